@@ -1,0 +1,213 @@
+/* include/pt_api.h — C-ABI drop-in boundary of the MI355X-native path tracer.
+ *
+ * One shared library (libptamd.so, built from pathtrace-on-cuda_amd/) exports exactly the
+ * entry points below.  Plain pointers and sizes only: no C++ types, no torch types.
+ * Citations `file:line` are relative to the reference tree (WaterPlease/PathTrace-on-CUDA).
+ * INTEGRATION.md shows the reference-side adaptor (`PathTracer::Render` re-implemented on
+ * top of these calls) a maintainer would add.
+ *
+ * Every function returns PT_OK (0) or a negative PtStatus and records a message that
+ * pt_last_error() returns (thread-local).  The reference's own convention for GPU errors
+ * — print to stderr, reset the device, exit(99) (include/CudaUtil.cuh:28-36) — is kept by
+ * the C++ adaptor `PathTracer::Render` (pathtrace-on-cuda_amd/host/pathtracer.cpp), not
+ * imposed on C callers.
+ */
+#ifndef PT_API_H
+#define PT_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_API __attribute__((visibility("default")))
+
+typedef enum PtStatus {
+    PT_OK = 0,
+    PT_ERR_INVALID = -1,      /* bad argument / inconsistent scene */
+    PT_ERR_NO_LIGHT = -2,     /* no emissive triangle: `curand(s) % Nl` is UB in the reference (include/CudaUtil.cuh:235) */
+    PT_ERR_DEVICE = -3,       /* HIP runtime error (message carries hipGetErrorString) */
+    PT_ERR_IO = -4,           /* file could not be read / written */
+    PT_ERR_UNSUPPORTED = -5   /* e.g. BVH deeper than the traversal stack */
+} PtStatus;
+
+/* ----------------------------------------------------------------------------------
+ * Host scene types: byte-compatible mirrors of the reference's host structs, so the
+ * adaptor can pass `bvh->primitives.data()` straight through.
+ * -------------------------------------------------------------------------------- */
+typedef struct PtVec3 { float x, y, z; } PtVec3;                 /* glm::vec3 */
+typedef struct PtVec2 { float x, y; } PtVec2;                    /* glm::vec2 */
+
+typedef struct PtMaterialOnCPU {                                 /* include/mesh.h:11-19 */
+    PtVec3 emittance, albedo, specular;
+    float opacity, metallic, roughness;
+} PtMaterialOnCPU;
+
+typedef struct PtVertex {                                        /* include/mesh.h:21-37, 112 B */
+    PtVec3 Position, Normal;
+    PtVec2 TexCoords;
+    PtVec3 Tangent, Bitangent;
+    PtMaterialOnCPU mat;
+    float u, v;
+} PtVertex;
+
+typedef struct PtPrimitive { PtVertex v1, v2, v3; } PtPrimitive; /* include/bvh.h:8-13, 336 B */
+
+typedef struct PtMaterial {                                      /* include/CudaPrimitive.cuh:15-23, 48 B */
+    float emittance[3], albedo[3], specular[3];
+    float opacity, roughness, metallic;
+} PtMaterial;
+
+typedef struct PtSphere {                                        /* include/CudaPrimitive.cuh:249-323 (data members), 64 B */
+    float center[3];
+    float rad;
+    PtMaterial mat;
+} PtSphere;
+
+typedef struct PtBVHNode {                                       /* CudaBVHNode, include/CudaPrimitive.cuh:237-247, 40 B */
+    float bMin[3], bMax[3];
+    int32_t childL, childR;                                      /* -1 = none */
+    int32_t primStart, primEnd;                                  /* inclusive range, -1 = interior */
+} PtBVHNode;
+
+/* Flattened triangle = the data members of the reference's `Triangle`
+ * (include/CudaPrimitive.cuh:217-234) after Triangle::Copy, without the vptr.  352 B. */
+typedef struct PtTriangle {
+    float V0[3], V1[3], V2[3];
+    float T0[3], T1[3], T2[3];
+    float B0[3], B1[3], B2[3];
+    float N0[3], N1[3], N2[3];
+    float normal[3], E1[3], E2[3];
+    float u0, v0, u1, v1, u2, v2;
+    PtMaterial mat0, mat1, mat2;
+    float area;
+} PtTriangle;
+
+typedef struct PtCamera {                                        /* what PathTracer::Render reads, srcs/pathtracer.cu:128-129,193-198 */
+    float pos[3];
+    float forward[3], up[3], right[3];                           /* Camera::GetForward/GetUp/GetRight */
+    float fovy_deg;                                              /* Camera::fovy (degrees) */
+    float aspect;                                                /* Camera::aspect */
+    int32_t W, H;                                                /* Camera::Screen_W / Screen_H */
+} PtCamera;
+
+typedef struct PtParams {                                        /* the reference's compile-time tunables, include/CudaUtil.cuh:15-19 */
+    int32_t passes;           /* NUM_MULTI_SAMPLE (8)   */
+    int32_t spp_per_pass;     /* NUM_SAMPLE (1024)      */
+    int32_t max_bounce;       /* MAX_BOUNCE (8)         */
+    int32_t rr_bounce;        /* RUSSIAN_ROULETTE_BOUNCE (3) */
+    float   rr_floor;         /* PROB_STOP_BOUNCE (0.5) */
+    int32_t max_refract;      /* the literal 8 of `RefractCnt++>8`, include/CudaUtil.cuh:354 */
+    int32_t first_pass;       /* SampleIDX of the first pass of this call (seed = offset + SampleIDX*W*H, srcs/pathtracer.cu:71) */
+    /* Tile split (new; the reference is single-device).  The frame is cut into 8x8-pixel
+     * tiles numbered row-major; this call renders tiles t with t % world == rank.
+     * world = 1, rank = 0 renders the whole frame. */
+    int32_t rank, world;
+} PtParams;
+
+PT_API void pt_params_default(PtParams* p);                      /* the reference's values */
+
+PT_API const char* pt_last_error(void);
+PT_API const char* pt_version(void);
+
+/* ----------------------------------------------------------------------------------
+ * (a1,a2) Host acceleration-structure build + flatten.
+ * Replaces SAHBVH::GenBVHTree (srcs/bvh.cpp:426-511) followed by LoadFromBVH
+ * (srcs/CudaPrimitive.cu:8-145) and the Triangle::Copy loop (srcs/pathtracer.cu:164-166).
+ * -------------------------------------------------------------------------------- */
+typedef struct PtFlatBVH PtFlatBVH;
+PT_API int  pt_bvh_build_sah(const PtPrimitive* prims, int32_t n_prims, PtFlatBVH** out);
+PT_API void pt_bvh_free(PtFlatBVH* b);
+PT_API int32_t pt_bvh_num_nodes(const PtFlatBVH* b);
+PT_API int32_t pt_bvh_num_tris(const PtFlatBVH* b);
+PT_API int32_t pt_bvh_max_depth(const PtFlatBVH* b);             /* "Maximum depth of tree", CudaPrimitive.cu:144 */
+PT_API const PtBVHNode*  pt_bvh_nodes(const PtFlatBVH* b);       /* == CudaBVH  */
+PT_API const PtTriangle* pt_bvh_tris(const PtFlatBVH* b);        /* == CudaPrims after Copy */
+
+/* ----------------------------------------------------------------------------------
+ * (a3) Scene upload.  Replaces the cudaMallocManaged + host-fill block of
+ * PathTracer::Render (srcs/pathtracer.cu:142-188).  `device` is the HIP device ordinal.
+ * The scene owns its HBM allocations until pt_scene_destroy.
+ * -------------------------------------------------------------------------------- */
+typedef struct PtScene PtScene;
+PT_API int  pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes,
+                            const PtTriangle* tris, int32_t n_tris,
+                            const PtSphere* spheres, int32_t n_spheres,
+                            int32_t device, PtScene** out);
+PT_API void pt_scene_destroy(PtScene* s);
+PT_API int32_t pt_scene_num_lights(const PtScene* s);            /* "ADD light" count, pathtracer.cu:167-173 */
+PT_API int64_t pt_scene_device_bytes(const PtScene* s);
+
+/* ----------------------------------------------------------------------------------
+ * (a3-a11) Render.  Replaces the StartRender launch loop (srcs/pathtracer.cu:236-246).
+ *
+ * pt_render_tiles: device-resident, asynchronous on `hip_stream` (a hipStream_t, may be
+ *   NULL).  Writes this rank's tiles, tile-major, into d_tiles:
+ *     d_tiles[((lt * 64) + (ty*8+tx)) * 3 + c],  lt = local tile index (global tile
+ *     t = lt*world + rank), float32, size pt_tiles_floats().  Value = sum over the call's
+ *     passes of the per-pass mean radiance (the reference's `image[offset] += mean`,
+ *     pathtracer.cu:81), starting from 0.  d_work is scratch of pt_work_bytes() bytes.
+ * pt_untile: scatter gathered tile buffers (rank-major: world buffers of
+ *   pt_tiles_floats() each) into a row-major W*H*3 frame, on the device.
+ * pt_render: convenience, whole frame (world=1) into a host buffer, synchronous;
+ *   h_accum_rgb[W*H*3] is overwritten.
+ * -------------------------------------------------------------------------------- */
+PT_API int64_t pt_tiles_floats(const PtCamera* cam, const PtParams* prm);
+PT_API int64_t pt_work_bytes(const PtCamera* cam, const PtParams* prm);
+PT_API int  pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm,
+                            float* d_tiles, void* d_work, void* hip_stream);
+PT_API int  pt_untile(const float* d_gathered, const PtCamera* cam, int32_t world,
+                      float* d_frame_rgb, void* hip_stream);
+PT_API int  pt_render(PtScene* s, const PtCamera* cam, const PtParams* prm, float* h_accum_rgb);
+/* Duration of the most recent pt_render_tiles launch sequence on this scene, measured with
+ * HIP events on the stream it was launched on (ms), and the kernel's own work counters. */
+PT_API int  pt_last_render_ms(PtScene* s, float* ms);
+
+/* ----------------------------------------------------------------------------------
+ * (a12,a13) Output + camera helpers (host).
+ * pt_tonemap_u8 = exportImage (srcs/pathtracer.cu:94-112): /SampleCnt, ACESFilm
+ *   (include/CudaUtil.cuh:383-391), ConverToUint8 (include/image.h:5-8).
+ * pt_write_png  = Image::WriteTo (srcs/image.cpp:22-25), RGB8.
+ * pt_camera_basis = Camera::SetRotation + GetRight (srcs/camera.cpp:32-66).
+ * -------------------------------------------------------------------------------- */
+PT_API int  pt_tonemap_u8(const float* raw_rgb, int64_t n_pixels, int32_t sample_cnt, uint8_t* rgb8);
+PT_API int  pt_write_png(const char* path, const uint8_t* data, int32_t W, int32_t H, int32_t channels);
+PT_API void pt_camera_basis(const float rot_deg[3], float forward[3], float up[3], float right[3]);
+
+/* ----------------------------------------------------------------------------------
+ * Synthetic scenes (the reference ships none: .gitignore:365, renderer.cpp:102-115 load
+ * absolute Windows paths).  Geometry exactly as SURVEY.md Appendix A.
+ *   kind 0: Cornell box (12 tris)                      kind 1: + 1 stand-in mesh (69,564 tris)
+ *   kind 2: + 4 instanced stand-ins (278,256 tris)
+ * lat_lon: tessellation of the stand-in (187 in the configs; smaller for tests).
+ * Returns the number of primitives; writes at most `cap` of them when prims != NULL.
+ * -------------------------------------------------------------------------------- */
+PT_API int32_t pt_scene_gen(int32_t kind, int32_t lat_lon, PtPrimitive* prims, int32_t cap);
+/* Minimal Wavefront OBJ(+MTL) reader producing the Vertex data Model::processMesh would
+ * (include/model.h:120-207) with BVH::AddModel's matrix bake (srcs/bvh.cpp:153-189):
+ * uniform `scale` then `translate`.  Same count/cap convention as pt_scene_gen. */
+PT_API int32_t pt_load_obj(const char* path, float scale, const float translate[3],
+                           PtPrimitive* prims, int32_t cap);
+
+/* ----------------------------------------------------------------------------------
+ * Parity hooks: run single device functions of the integrator on the GPU so tests can
+ * compare them with the oracle record by record (host pointers in and out).
+ * Record layouts are those of oracle/pt_oracle.h (RAY8, HIT(29 f), BXDF in 28 f / out 12 f).
+ * -------------------------------------------------------------------------------- */
+PT_API int  pt_dbg_raycast(PtScene* s, const float* rays8, int32_t n, float* out_hits29, int32_t* out_prim);
+PT_API int  pt_dbg_bxdf(int32_t device, int32_t lobe, const float* in28, int32_t n, float* out12);
+PT_API int  pt_dbg_rng(int32_t device, uint64_t seed, int32_t n, uint32_t* raw_out, float* uniform_out);
+PT_API int  pt_dbg_math(int32_t device, const float* in, int32_t n, float* out8);
+/* Work counters of the last pt_render_tiles on this scene (int64 x 8):
+ * [0] rays [1] node records fetched [2] triangle tests [3] sphere tests [4] rays with hit
+ * [5] camera paths [6] loop trips of the wave scheduler [7] lane-trips with an active ray */
+PT_API int  pt_last_counters(PtScene* s, int64_t* out8);
+/* Run the counting build of the kernel on the next pt_render_tiles calls (slower). */
+PT_API int  pt_enable_counters(PtScene* s, int32_t on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_API_H */

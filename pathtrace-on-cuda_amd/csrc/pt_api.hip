@@ -1,0 +1,395 @@
+// pt_api.hip — device half of the C-ABI (include/pt_api.h): scene upload into the HBM
+// layout of pt_device.h, render launch sequence, tile gather helpers, parity hooks.
+//
+// Replaces the body of PathTracer::Render (srcs/pathtracer.cu:124-259): instead of five
+// cudaMallocManaged regions filled element by element from the host and a device vtable
+// plant, the scene is repacked once on the host into 16-byte records and copied with one
+// hipMemcpy per array; instead of NUM_MULTI_SAMPLE synchronous launches there is one
+// persistent launch over all (tile, pass) units on the caller's stream.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_api.h"
+#include "pt_device.h"
+
+extern "C" {
+hipError_t ptk_render_units(const ptd::DevScene*, const ptd::DevCamera*, const ptd::DevParams*, float*, unsigned int*, void*, int, int, hipStream_t);
+hipError_t ptk_sum_passes(const float*, int, long long, float*, hipStream_t);
+hipError_t ptk_untile(const float*, int, int, int, int, int, long long, float*, hipStream_t);
+hipError_t ptk_dbg_raycast(const ptd::DevScene*, const float*, int, float*, int*, hipStream_t);
+hipError_t ptk_dbg_bxdf(int, const float*, int, float*, hipStream_t);
+hipError_t ptk_dbg_rng(unsigned long long, int, uint32_t*, float*, hipStream_t);
+hipError_t ptk_dbg_math(const float*, int, float*, hipStream_t);
+}
+
+void pt_set_error(const char* fmt, ...);   // pt_host.cpp
+
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            pt_set_error("HIP error %d at %s:%d '%s': %s", (int)e_, __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            return PT_ERR_DEVICE;                                                           \
+        }                                                                                   \
+    } while (0)
+
+struct PtScene {
+    int device = 0;
+    ptd::DevScene dev{};
+    void* d_nodes = nullptr; void* d_tri = nullptr; void* d_shade = nullptr; void* d_mats = nullptr;
+    void* d_lights = nullptr; void* d_spheres = nullptr;
+    unsigned int* d_unit_counter = nullptr;
+    void* d_counters = nullptr;
+    int64_t bytes = 0;
+    int n_lights = 0;
+    int max_depth = 0;
+    int num_cus = 256;
+    bool count_next = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+
+static int upload(void** dptr, const void* h, size_t bytes, int64_t& total)
+{
+    size_t alloc = bytes ? bytes : 16;
+    HIPCHK(hipMalloc(dptr, alloc));
+    if (bytes) HIPCHK(hipMemcpy(*dptr, h, bytes, hipMemcpyHostToDevice));
+    total += (int64_t)alloc;
+    return PT_OK;
+}
+
+static inline float as_float(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
+
+template <class F>
+static int with_buffers(int device, const void* in, size_t in_bytes, void* out, size_t out_bytes, void* out2, size_t out2_bytes, F launch)
+{
+    HIPCHK(hipSetDevice(device));
+    void *d_in = nullptr, *d_out = nullptr, *d_out2 = nullptr;
+    HIPCHK(hipMalloc(&d_in, in_bytes ? in_bytes : 16));
+    HIPCHK(hipMalloc(&d_out, out_bytes ? out_bytes : 16));
+    HIPCHK(hipMalloc(&d_out2, out2_bytes ? out2_bytes : 16));
+    if (in_bytes) HIPCHK(hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice));
+    HIPCHK(launch(d_in, d_out, d_out2));
+    HIPCHK(hipDeviceSynchronize());
+    if (out_bytes) HIPCHK(hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost));
+    if (out2_bytes) HIPCHK(hipMemcpy(out2, d_out2, out2_bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_out2);
+    return PT_OK;
+}
+
+
+extern "C" {
+
+int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* tris, int32_t n_tris,
+                    const PtSphere* spheres, int32_t n_spheres, int32_t device, PtScene** out)
+{
+    if (!out) { pt_set_error("pt_scene_create: out is NULL"); return PT_ERR_INVALID; }
+    *out = nullptr;
+    if (!nodes || n_nodes < 1 || !tris || n_tris < 1 || n_spheres < 0 || (n_spheres > 0 && !spheres)) {
+        pt_set_error("pt_scene_create: empty or NULL scene arrays (n_nodes=%d n_tris=%d n_spheres=%d)", n_nodes, n_tris, n_spheres);
+        return PT_ERR_INVALID;
+    }
+    // ---- validate the flattened tree and measure its depth (host check before any kernel sees it) ----
+    std::vector<int> depth((size_t)n_nodes, -1);
+    std::vector<int> widx((size_t)n_nodes, -1);
+    int n_wide = 0, max_depth = 0;
+    {
+        std::vector<int> st; st.push_back(0); depth[0] = 0;
+        std::vector<char> seen((size_t)n_nodes, 0);
+        while (!st.empty()) {
+            int i = st.back(); st.pop_back();
+            if (seen[(size_t)i]) { pt_set_error("pt_scene_create: node %d reachable twice", i); return PT_ERR_INVALID; }
+            seen[(size_t)i] = 1;
+            const PtBVHNode& n = nodes[i];
+            if (depth[i] > max_depth) max_depth = depth[i];
+            const bool leaf = (n.primStart != -1 && n.primEnd != -1);
+            if (leaf) {
+                if (n.primStart < 0 || n.primEnd < n.primStart || n.primEnd >= n_tris || n.primEnd - n.primStart + 1 > 7) {
+                    pt_set_error("pt_scene_create: leaf %d has bad primitive range [%d,%d]", i, n.primStart, n.primEnd);
+                    return PT_ERR_INVALID;
+                }
+                if (n.childL > 0 || n.childR > 0) { pt_set_error("pt_scene_create: leaf %d has children", i); return PT_ERR_INVALID; }
+            } else {
+                if (n.childL <= 0 || n.childR <= 0 || n.childL >= n_nodes || n.childR >= n_nodes) {
+                    pt_set_error("pt_scene_create: interior node %d has bad children (%d,%d)", i, n.childL, n.childR);
+                    return PT_ERR_INVALID;
+                }
+                widx[(size_t)i] = 0;    // numbered below, in index order (= the reference's pre-order)
+                depth[n.childL] = depth[i] + 1; depth[n.childR] = depth[i] + 1;
+                st.push_back(n.childR); st.push_back(n.childL);
+            }
+        }
+    }
+    if (max_depth > ptd::kStackDepth) {
+        pt_set_error("pt_scene_create: BVH depth %d exceeds the traversal stack (%d)", max_depth, ptd::kStackDepth);
+        return PT_ERR_UNSUPPORTED;
+    }
+    for (int i = 0; i < n_nodes; i++) if (widx[(size_t)i] == 0) widx[(size_t)i] = n_wide++;
+
+    // ---- wide nodes ----
+    auto ref_of = [&](int child) -> int32_t {
+        const PtBVHNode& c = nodes[child];
+        if (c.primStart != -1 && c.primEnd != -1) return ~((c.primStart << 3) | (c.primEnd - c.primStart + 1));
+        return widx[(size_t)child];
+    };
+    std::vector<float> wide;
+    auto push_wide = [&](const PtBVHNode& L, int32_t refL, const PtBVHNode& R, int32_t refR) {
+        const float rec[16] = {L.bMin[0], L.bMin[1], L.bMin[2], L.bMax[0], L.bMax[1], L.bMax[2], R.bMin[0], R.bMin[1],
+                               R.bMin[2], R.bMax[0], R.bMax[1], R.bMax[2], as_float(refL), as_float(refR), 0.f, 0.f};
+        wide.insert(wide.end(), rec, rec + 16);
+    };
+    if (n_wide == 0) {
+        // the root is a leaf: one record whose L side is the root itself and whose R side is "no child"
+        push_wide(nodes[0], ref_of(0), nodes[0], ~0);
+        n_wide = 1;
+    } else {
+        wide.reserve((size_t)n_wide * 16);
+        for (int i = 0; i < n_nodes; i++) {
+            if (widx[(size_t)i] < 0) continue;
+            const PtBVHNode& n = nodes[i];
+            push_wide(nodes[n.childL], ref_of(n.childL), nodes[n.childR], ref_of(n.childR));
+        }
+    }
+
+    // ---- triangles: test records, shade records, de-duplicated materials, lights ----
+    std::vector<float> tri((size_t)n_tris * 12), shade((size_t)n_tris * 28), mats, lights;
+    std::map<std::string, int> matIndex;
+    int n_lights = 0;
+    for (int i = 0; i < n_tris; i++) {
+        const PtTriangle& t = tris[i];
+        float* a = &tri[(size_t)i * 12];
+        a[0] = t.V0[0]; a[1] = t.V0[1]; a[2] = t.V0[2]; a[3] = 0.f;
+        a[4] = t.E1[0]; a[5] = t.E1[1]; a[6] = t.E1[2]; a[7] = 0.f;
+        a[8] = t.E2[0]; a[9] = t.E2[1]; a[10] = t.E2[2]; a[11] = 0.f;
+        float* s = &shade[(size_t)i * 28];
+        const float* src[9] = {t.N0, t.N1, t.N2, t.T0, t.T1, t.T2, t.B0, t.B1, t.B2};
+        for (int k = 0; k < 9; k++) { s[3 * k] = src[k][0]; s[3 * k + 1] = src[k][1]; s[3 * k + 2] = src[k][2]; }
+        std::string key((const char*)&t.mat0, sizeof(PtMaterial));
+        auto it = matIndex.find(key);
+        int mi;
+        if (it == matIndex.end()) {
+            mi = (int)matIndex.size();
+            matIndex[key] = mi;
+            const PtMaterial& m = t.mat0;       // Triangle::hit copies mat0 only (CudaPrimitive.cuh:149-154)
+            const float rec[12] = {m.emittance[0], m.emittance[1], m.emittance[2], m.albedo[0], m.albedo[1], m.albedo[2],
+                                   m.specular[0], m.specular[1], m.specular[2], m.opacity, m.roughness, m.metallic};
+            mats.insert(mats.end(), rec, rec + 12);
+        } else mi = it->second;
+        s[27] = as_float(mi);
+        auto len = [](const float* e) { return std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]); };
+        if (len(t.mat0.emittance) > 0.0001f || len(t.mat1.emittance) > 0.0001f || len(t.mat2.emittance) > 0.0001f) {
+            const float rec[16] = {t.V0[0], t.V0[1], t.V0[2], t.V1[0], t.V1[1], t.V1[2], t.V2[0], t.V2[1], t.V2[2],
+                                   t.normal[0], t.normal[1], t.normal[2], t.area, 0.f, 0.f, 0.f};
+            lights.insert(lights.end(), rec, rec + 16);
+            n_lights++;
+        }
+    }
+    std::vector<float> sph((size_t)n_spheres * 16);
+    for (int i = 0; i < n_spheres; i++) {
+        const PtSphere& s = spheres[i];
+        float* a = &sph[(size_t)i * 16];
+        a[0] = s.center[0]; a[1] = s.center[1]; a[2] = s.center[2]; a[3] = s.rad;
+        memcpy(a + 4, &s.mat, sizeof(PtMaterial));
+    }
+
+    HIPCHK(hipSetDevice(device));
+    PtScene* sc = new PtScene();
+    sc->device = device;
+    sc->n_lights = n_lights;
+    sc->max_depth = max_depth;
+    int rc;
+    if ((rc = upload(&sc->d_nodes, wide.data(), wide.size() * 4, sc->bytes)) ||
+        (rc = upload(&sc->d_tri, tri.data(), tri.size() * 4, sc->bytes)) ||
+        (rc = upload(&sc->d_shade, shade.data(), shade.size() * 4, sc->bytes)) ||
+        (rc = upload(&sc->d_mats, mats.data(), mats.size() * 4, sc->bytes)) ||
+        (rc = upload(&sc->d_lights, lights.data(), lights.size() * 4, sc->bytes)) ||
+        (rc = upload(&sc->d_spheres, sph.data(), sph.size() * 4, sc->bytes))) {
+        pt_scene_destroy(sc);
+        return rc;
+    }
+    HIPCHK(hipMalloc((void**)&sc->d_unit_counter, 64));
+    HIPCHK(hipMalloc(&sc->d_counters, 64));
+    HIPCHK(hipMemset(sc->d_counters, 0, 64));
+    HIPCHK(hipEventCreate(&sc->ev0));
+    HIPCHK(hipEventCreate(&sc->ev1));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    sc->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    sc->dev.nodes = (const float4*)sc->d_nodes; sc->dev.tri = (const float4*)sc->d_tri;
+    sc->dev.shade = (const float4*)sc->d_shade; sc->dev.mats = (const float4*)sc->d_mats;
+    sc->dev.lights = (const float4*)sc->d_lights; sc->dev.spheres = (const float4*)sc->d_spheres;
+    sc->dev.n_nodes = n_wide; sc->dev.n_tris = n_tris; sc->dev.n_lights = n_lights; sc->dev.n_spheres = n_spheres;
+    *out = sc;
+    return PT_OK;
+}
+
+void pt_scene_destroy(PtScene* s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    void* p[] = {s->d_nodes, s->d_tri, s->d_shade, s->d_mats, s->d_lights, s->d_spheres, s->d_unit_counter, s->d_counters};
+    for (void* q : p) if (q) (void)hipFree(q);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    delete s;
+}
+
+int32_t pt_scene_num_lights(const PtScene* s) { return s ? s->n_lights : 0; }
+int64_t pt_scene_device_bytes(const PtScene* s) { return s ? s->bytes : 0; }
+
+// ---- geometry of the tile split --------------------------------------------------------
+static int fill_params(const PtCamera* cam, const PtParams* prm, ptd::DevParams& d)
+{
+    if (!cam || !prm) { pt_set_error("NULL camera/params"); return PT_ERR_INVALID; }
+    if (cam->W < 2 || cam->H < 2) { pt_set_error("frame %dx%d too small (W-1, H-1 divide, srcs/pathtracer.cu:35-36)", cam->W, cam->H); return PT_ERR_INVALID; }
+    if (prm->passes < 1 || prm->spp_per_pass < 1 || prm->max_bounce < 1 || prm->world < 1 || prm->rank < 0 || prm->rank >= prm->world) {
+        pt_set_error("bad params: passes=%d spp=%d max_bounce=%d rank=%d world=%d", prm->passes, prm->spp_per_pass, prm->max_bounce, prm->rank, prm->world);
+        return PT_ERR_INVALID;
+    }
+    const long long maxseed = (long long)cam->W * cam->H * (long long)(prm->first_pass + prm->passes);
+    if (maxseed > 0x7fffffffLL) { pt_set_error("offset + SampleIDX*W*H overflows int (srcs/pathtracer.cu:71)"); return PT_ERR_INVALID; }
+    d.passes = prm->passes; d.spp_per_pass = prm->spp_per_pass; d.max_bounce = prm->max_bounce; d.rr_bounce = prm->rr_bounce;
+    d.rr_floor = prm->rr_floor; d.max_refract = prm->max_refract; d.first_pass = prm->first_pass;
+    d.rank = prm->rank; d.world = prm->world;
+    d.tiles_x = (cam->W + ptd::kTile - 1) / ptd::kTile;
+    d.tiles_y = (cam->H + ptd::kTile - 1) / ptd::kTile;
+    d.n_tiles_total = d.tiles_x * d.tiles_y;
+    d.n_tiles_local = (d.n_tiles_total + prm->world - 1) / prm->world;
+    const long long units = (long long)d.n_tiles_local * prm->passes;
+    if (units > 0x7fffffffLL) { pt_set_error("too many work units"); return PT_ERR_INVALID; }
+    d.n_units = (int)units;
+    return PT_OK;
+}
+
+int64_t pt_tiles_floats(const PtCamera* cam, const PtParams* prm)
+{
+    ptd::DevParams d;
+    if (fill_params(cam, prm, d)) return -1;
+    return (int64_t)d.n_tiles_local * ptd::kTilePixels * 3;
+}
+int64_t pt_work_bytes(const PtCamera* cam, const PtParams* prm)
+{
+    ptd::DevParams d;
+    if (fill_params(cam, prm, d)) return -1;
+    return (int64_t)d.n_tiles_local * ptd::kTilePixels * 3 * 4 * prm->passes;
+}
+
+int pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm, float* d_tiles, void* d_work, void* hip_stream)
+{
+    if (!s || !d_tiles || !d_work) { pt_set_error("pt_render_tiles: NULL argument"); return PT_ERR_INVALID; }
+    if (s->n_lights < 1) {
+        pt_set_error("scene has no emissive triangle: the reference's `curand(s) %% Nl` is undefined (include/CudaUtil.cuh:235)");
+        return PT_ERR_NO_LIGHT;
+    }
+    ptd::DevParams d;
+    int rc = fill_params(cam, prm, d);
+    if (rc) return rc;
+    ptd::DevCamera c;
+    memcpy(c.pos, cam->pos, 12); memcpy(c.forward, cam->forward, 12); memcpy(c.up, cam->up, 12); memcpy(c.right, cam->right, 12);
+    c.W = cam->W; c.H = cam->H;
+    // srcs/pathtracer.cu:197-198 and :35-36 — correctly rounded float tan/atan2
+    const float fovy = cam->fovy_deg * 0.01745329251994329576923690768489f;                 // glm::radians
+    const float fovx = 2.f * (float)std::atan2((double)((float)std::tan((double)(fovy * 0.5f)) * cam->aspect), 1.0);
+    c.tan_half_fovx = (float)std::tan((double)(fovx * 0.5f));
+    c.tan_half_fovy = (float)std::tan((double)(fovy * 0.5f));
+
+    hipStream_t stream = (hipStream_t)hip_stream;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipEventRecord(s->ev0, stream));
+    HIPCHK(hipMemsetAsync(s->d_unit_counter, 0, 4, stream));
+    if (s->count_next) HIPCHK(hipMemsetAsync(s->d_counters, 0, 64, stream));
+    // persistent grid: 4 blocks of 4 waves per CU (16 waves/CU; register- and LDS-feasible), never more blocks than units need
+    int blocks = s->num_cus * 4;
+    const int need = (d.n_units + ptd::kWavesPerBlock - 1) / ptd::kWavesPerBlock;
+    if (blocks > need) blocks = need;
+    if (blocks < 1) blocks = 1;
+    HIPCHK(ptk_render_units(&s->dev, &c, &d, (float*)d_work, s->d_unit_counter, s->d_counters, blocks, s->count_next ? 1 : 0, stream));
+    HIPCHK(ptk_sum_passes((const float*)d_work, d.passes, (long long)d.n_tiles_local * ptd::kTilePixels * 3, d_tiles, stream));
+    HIPCHK(hipEventRecord(s->ev1, stream));
+    s->timed = true;
+    return PT_OK;
+}
+
+int pt_untile(const float* d_gathered, const PtCamera* cam, int32_t world, float* d_frame_rgb, void* hip_stream)
+{
+    if (!d_gathered || !cam || !d_frame_rgb || world < 1) { pt_set_error("pt_untile: bad argument"); return PT_ERR_INVALID; }
+    const int tiles_x = (cam->W + ptd::kTile - 1) / ptd::kTile, tiles_y = (cam->H + ptd::kTile - 1) / ptd::kTile;
+    const int n_total = tiles_x * tiles_y;
+    const long long per_rank = (long long)((n_total + world - 1) / world) * ptd::kTilePixels * 3;
+    HIPCHK(ptk_untile(d_gathered, cam->W, cam->H, tiles_x, n_total, world, per_rank, d_frame_rgb, (hipStream_t)hip_stream));
+    return PT_OK;
+}
+
+int pt_render(PtScene* s, const PtCamera* cam, const PtParams* prm, float* h_accum_rgb)
+{
+    if (!s || !h_accum_rgb || !prm) { pt_set_error("pt_render: NULL argument"); return PT_ERR_INVALID; }
+    PtParams p = *prm; p.rank = 0; p.world = 1;
+    const int64_t nt = pt_tiles_floats(cam, &p), wb = pt_work_bytes(cam, &p);
+    if (nt < 0 || wb < 0) return PT_ERR_INVALID;
+    HIPCHK(hipSetDevice(s->device));
+    float *d_tiles = nullptr, *d_frame = nullptr; void* d_work = nullptr;
+    HIPCHK(hipMalloc((void**)&d_tiles, (size_t)nt * 4));
+    HIPCHK(hipMalloc(&d_work, (size_t)wb));
+    HIPCHK(hipMalloc((void**)&d_frame, (size_t)cam->W * cam->H * 12));
+    int rc = pt_render_tiles(s, cam, &p, d_tiles, d_work, nullptr);
+    if (!rc) rc = pt_untile(d_tiles, cam, 1, d_frame, nullptr);
+    if (!rc) {
+        hipError_t e = hipMemcpy(h_accum_rgb, d_frame, (size_t)cam->W * cam->H * 12, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { pt_set_error("hipMemcpy D2H: %s", hipGetErrorString(e)); rc = PT_ERR_DEVICE; }
+    }
+    (void)hipFree(d_tiles); (void)hipFree(d_work); (void)hipFree(d_frame);
+    return rc;
+}
+
+int pt_last_render_ms(PtScene* s, float* ms)
+{
+    if (!s || !ms || !s->timed) { pt_set_error("pt_last_render_ms: nothing rendered yet"); return PT_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipEventSynchronize(s->ev1));
+    HIPCHK(hipEventElapsedTime(ms, s->ev0, s->ev1));
+    return PT_OK;
+}
+
+int pt_last_counters(PtScene* s, int64_t* out8)
+{
+    if (!s || !out8) { pt_set_error("pt_last_counters: NULL"); return PT_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out8, s->d_counters, 64, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+// Ask the next pt_render_tiles on this scene to run the counting build of the kernel.
+PT_API int pt_enable_counters(PtScene* s, int32_t on) { if (!s) return PT_ERR_INVALID; s->count_next = on != 0; return PT_OK; }
+
+// ---- parity hooks ------------------------------------------------------------------------
+int pt_dbg_raycast(PtScene* s, const float* rays8, int32_t n, float* out_hits29, int32_t* out_prim)
+{
+    if (!s || !rays8 || n < 0 || !out_hits29 || !out_prim) { pt_set_error("pt_dbg_raycast: bad argument"); return PT_ERR_INVALID; }
+    return with_buffers(s->device, rays8, (size_t)n * 32, out_hits29, (size_t)n * 29 * 4, out_prim, (size_t)n * 4,
+                        [&](void* i, void* o, void* o2) { return ptk_dbg_raycast(&s->dev, (const float*)i, n, (float*)o, (int*)o2, nullptr); });
+}
+int pt_dbg_bxdf(int32_t device, int32_t lobe, const float* in28, int32_t n, float* out12)
+{
+    if (!in28 || !out12 || n < 0 || lobe < 0 || lobe > 3) { pt_set_error("pt_dbg_bxdf: bad argument"); return PT_ERR_INVALID; }
+    return with_buffers(device, in28, (size_t)n * 28 * 4, out12, (size_t)n * 12 * 4, nullptr, 0,
+                        [&](void* i, void* o, void*) { return ptk_dbg_bxdf(lobe, (const float*)i, n, (float*)o, nullptr); });
+}
+int pt_dbg_rng(int32_t device, uint64_t seed, int32_t n, uint32_t* raw_out, float* uniform_out)
+{
+    if (!raw_out || !uniform_out || n < 0) { pt_set_error("pt_dbg_rng: bad argument"); return PT_ERR_INVALID; }
+    return with_buffers(device, nullptr, 0, raw_out, (size_t)n * 4, uniform_out, (size_t)n * 4,
+                        [&](void*, void* o, void* o2) { return ptk_dbg_rng(seed, n, (uint32_t*)o, (float*)o2, nullptr); });
+}
+int pt_dbg_math(int32_t device, const float* in, int32_t n, float* out8)
+{
+    if (!in || !out8 || n < 0) { pt_set_error("pt_dbg_math: bad argument"); return PT_ERR_INVALID; }
+    return with_buffers(device, in, (size_t)n * 4, out8, (size_t)n * 8 * 4, nullptr, 0,
+                        [&](void* i, void* o, void*) { return ptk_dbg_math((const float*)i, n, (float*)o, nullptr); });
+}
+
+}  // extern "C"

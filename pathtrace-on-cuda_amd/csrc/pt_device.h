@@ -1,0 +1,58 @@
+// pt_device.h — HBM data layout of an uploaded scene and the kernel argument blocks.
+// Shared by the host upload code (pt_api.hip) and the kernels (pt_kernels.hip).
+//
+// Everything is 16-byte records read with one global_load_dwordx4 per float4:
+//
+//  wide node (64 B, 4 x float4) — one per INTERIOR node of the reference's flattened tree
+//      (CudaBVHNode[], include/CudaPrimitive.cuh:237-247), holding BOTH children's boxes so
+//      one dependent fetch decides two box tests:
+//        q0 = Lmin.x Lmin.y Lmin.z Lmax.x
+//        q1 = Lmax.y Lmax.z Rmin.x Rmin.y
+//        q2 = Rmin.z Rmax.x Rmax.y Rmax.z
+//        q3 = refL refR (int bits) | unused | unused
+//      L = the reference's childL (= flat index + 1), R = childR.
+//      ref >= 0 : index of the child's own wide node
+//      ref <  0 : leaf, ~ref = (primStart << 3) | primCount   (primCount 0 = "no child")
+//  tri test record (48 B, 3 x float4):  (V0,0) (E1,0) (E2,0)        — all a box/triangle test reads
+//  tri shade record (112 B, 7 x float4): N0 N1 N2 T0 T1 T2 B0 B1 B2 (27 f) + material index
+//      read once per accepted closest hit
+//  material (48 B, 3 x float4): emittance albedo specular opacity roughness metallic
+//  light (64 B, 4 x float4): V0 V1 V2 normal area (13 f)            — srcs/pathtracer.cu:164-174
+//  sphere (64 B, 4 x float4): center rad | material (12 f)
+#pragma once
+#include <stdint.h>
+
+namespace ptd {
+
+constexpr int kTile = 8;                 // tiles are 8x8 pixels = one wavefront
+constexpr int kTilePixels = 64;
+constexpr int kStackDepth = 32;          // per-lane traversal stack entries (LDS)
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlockThreads = 64 * kWavesPerBlock;
+
+struct DevScene {
+    const float4* nodes;
+    const float4* tri;
+    const float4* shade;
+    const float4* mats;
+    const float4* lights;
+    const float4* spheres;
+    int32_t n_nodes, n_tris, n_lights, n_spheres;
+};
+
+struct DevCamera {
+    float pos[3], forward[3], up[3], right[3];
+    float tan_half_fovx, tan_half_fovy;  // tan(CameraFovX*0.5f), tan(CameraFovY*0.5f): per-launch constants of GetPixelDirection
+    int32_t W, H;
+};
+
+struct DevParams {
+    int32_t passes, spp_per_pass, max_bounce, rr_bounce;
+    float rr_floor;
+    int32_t max_refract, first_pass;
+    int32_t rank, world;
+    int32_t tiles_x, tiles_y, n_tiles_total, n_tiles_local;
+    int32_t n_units;                     // n_tiles_local * passes
+};
+
+}  // namespace ptd

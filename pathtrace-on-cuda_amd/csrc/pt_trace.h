@@ -1,0 +1,156 @@
+// pt_trace.h — closest-hit query over the wide-node BVH, one ray per lane (wave64).
+//
+// What it must reproduce: RayCast (include/CudaUtil.cuh:93-148) — closest hit over all
+// triangles in [t_min, t_max], then the linear sphere loop — including its tie rule: a hit
+// with t == closestT REPLACES the incumbent (Triangle::hit rejects only t > t_max,
+// include/CudaPrimitive.cuh:104-108), so among equal t the largest primitive index wins and
+// spheres (tested last, in order) beat triangles.
+//
+// How it differs: the reference walks a 40-byte-per-node array
+// depth-first in index order with a 128-entry local-memory stack and culls boxes only
+// against an un-scaled closestT.  Here one 64-byte record holds both children's boxes,
+// children are visited near-first, far children go to a per-lane LDS stack, and boxes are
+// additionally culled against the current closest hit (with 2^-7 relative slack so a box is
+// never dropped on float rounding).  The *slab part* of the box test is the reference's own
+// arithmetic (intersectionAABB, CudaUtil.cuh:65-88: inverse direction normalised, far side
+// scaled by 1.00000024f), so the set of leaves whose box passes is the reference's set
+// minus boxes that lie strictly beyond the closest hit.  The final (t, primitive) is
+// therefore the reference's.
+#pragma once
+#include "pt_device.h"
+#include "pt_math.h"
+
+namespace ptd {
+
+struct TraceStats { uint32_t nodes, tris, spheres; };
+
+// Reference slab arithmetic for one box.  Returns the scaled entry distance in tn.
+PT_DEV bool box_test(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz,
+                     const f3& org, const f3& invD, float cullB, bool degenerate, float& tn)
+{
+    float x1 = (bminx - org.x) * invD.x, x2 = (bmaxx - org.x) * invD.x;
+    float y1 = (bminy - org.y) * invD.y, y2 = (bmaxy - org.y) * invD.y;
+    float z1 = (bminz - org.z) * invD.z, z2 = (bmaxz - org.z) * invD.z;
+    float txmin = __builtin_fminf(x1, x2), txmax = __builtin_fmaxf(x1, x2);
+    float tymin = __builtin_fminf(y1, y2), tymax = __builtin_fmaxf(y1, y2);
+    float tzmin = __builtin_fminf(z1, z2), tzmax = __builtin_fmaxf(z1, z2);
+    tn = __builtin_fmaxf(tzmin, __builtin_fmaxf(tymin, __builtin_fmaxf(txmin, 0.f)));
+    float tf = __builtin_fminf(tzmax, __builtin_fminf(tymax, txmax));
+    tf *= 1.00000024f;
+    // A ray with a zero / non-finite direction component makes the reference's normalised
+    // inverse direction NaN/0 and its test accept every box (CudaVector.cuh:226-234 select
+    // semantics); `degenerate` reproduces that.
+    return degenerate | ((tn <= tf) & (tn <= cullB));
+}
+
+// Moeller-Trumbore with the reference's back-face cull and test order,
+// Triangle::hit, include/CudaPrimitive.cuh:89-118.
+PT_DEV void tri_test(const float4* __restrict__ tri, int i, const f3& org, const f3& dir,
+                     float& bestT, int& bestPrim)
+{
+    const float4 a = tri[3 * i], b = tri[3 * i + 1], c = tri[3 * i + 2];
+    const f3 V0(a.x, a.y, a.z), E1(b.x, b.y, b.z), E2(c.x, c.y, c.z);
+    const f3 T = org - V0;
+    const f3 P = cross(dir, E2);
+    const f3 Q = cross(T, E1);
+    const float det = dot(P, E1);
+    if (det < kEps) return;
+    const float invDet = 1.f / det;
+    const float t = dot(Q, E2) * invDet;
+    if (t < 0.f || t > bestT) return;
+    const float u = dot(P, T);
+    if (u < 0.f || u > det) return;
+    const float v = dot(Q, dir);
+    if (v < 0.f || (v + u) > det) return;
+    if (t < bestT || i > bestPrim) { bestT = t; bestPrim = i; }
+}
+
+// Sphere::hit root selection, include/CudaPrimitive.cuh:255-272.
+PT_DEV bool sphere_root(const f3& center, float rad, const f3& org, const f3& dir, float tmax, float& root)
+{
+    const f3 oc = org - center;
+    const float a = sqlen(dir);
+    const float half_b = dot(oc, dir);
+    const float c = sqlen(oc) - rad * rad;
+    const float disc = half_b * half_b - a * c;
+    if (disc < 0.f) return false;
+    const float sq = __builtin_sqrtf(disc);
+    root = (-half_b - sq) / a;
+    if (root < 0.f || tmax < root) {
+        root = (-half_b + sq) / a;
+        if (root < 0.f || tmax < root) return false;
+    }
+    return true;
+}
+
+// Closest hit of (org, dir) in [0, tmax].  `stack` points at this lane's column of the
+// wave's LDS stack: entry k lives at stack[k * 64].
+// Returns primitive index (triangle i, n_tris + sphere j) or -1; bestT = its t.
+template <bool COUNT>
+PT_DEV int trace_closest(const DevScene& sc, const f3& org, const f3& dir, float tmax,
+                         int* stack, float& bestT, TraceStats& st)
+{
+    const f3 inv(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);                    // inv(), CudaUtil.cuh:60-63
+    const float L = __builtin_sqrtf(inv.x * inv.x + inv.y * inv.y + inv.z * inv.z);
+    const f3 invD = inv / L;                                                 // Normalize(inv(dir)), :70
+    const bool degenerate = !(L < __builtin_inff());
+    const float kcull = 1.0078125f / L;     // un-scales the reference's scaled entry distance, +2^-7 slack
+    bestT = tmax;
+    int bestPrim = -1;
+    float cullB = bestT * kcull;
+
+    int sp = 0;
+    int cur = 0;
+    for (;;) {
+        const float4 q0 = sc.nodes[4 * cur + 0];
+        const float4 q1 = sc.nodes[4 * cur + 1];
+        const float4 q2 = sc.nodes[4 * cur + 2];
+        const float4 q3 = sc.nodes[4 * cur + 3];
+        if (COUNT) st.nodes++;
+        float tnL, tnR;
+        bool okL = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, org, invD, cullB, degenerate, tnL);
+        bool okR = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, org, invD, cullB, degenerate, tnR);
+        const int refL = __float_as_int(q3.x), refR = __float_as_int(q3.y);
+
+        if (okL && refL < 0) {
+            const int code = ~refL, first = code >> 3, cnt = code & 7;
+            for (int k = 0; k < cnt; k++) { tri_test(sc.tri, first + k, org, dir, bestT, bestPrim); if (COUNT) st.tris++; }
+            cullB = bestT * kcull;
+            okL = false;
+        }
+        if (okR && refR < 0) {
+            // re-check against the possibly tightened bound (result-neutral: skips boxes beyond the hit)
+            if (degenerate | (tnR <= cullB)) {
+                const int code = ~refR, first = code >> 3, cnt = code & 7;
+                for (int k = 0; k < cnt; k++) { tri_test(sc.tri, first + k, org, dir, bestT, bestPrim); if (COUNT) st.tris++; }
+                cullB = bestT * kcull;
+            }
+            okR = false;
+        }
+        if (okL & okR) {
+            const bool lNear = tnL <= tnR;
+            stack[sp * 64] = lNear ? refR : refL;
+            sp++;
+            cur = lNear ? refL : refR;
+        } else if (okL) {
+            cur = refL;
+        } else if (okR) {
+            cur = refR;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            cur = stack[sp * 64];
+        }
+    }
+
+    // spheres, in order, against the triangles' closest t (CudaUtil.cuh:137-145)
+    for (int s = 0; s < sc.n_spheres; s++) {
+        const float4 c = sc.spheres[4 * s];
+        float root;
+        if (COUNT) st.spheres++;
+        if (sphere_root(f3(c.x, c.y, c.z), c.w, org, dir, bestT, root)) { bestT = root; bestPrim = sc.n_tris + s; }
+    }
+    return bestPrim;
+}
+
+}  // namespace ptd

@@ -1,0 +1,297 @@
+"""ptamd — Python binding of the C-ABI in include/pt_api.h (libptamd.so).
+
+This is plumbing only: ctypes declarations, numpy views of the C structs and thin
+wrappers.  The renderer itself is the HIP library; nothing here computes radiance, and
+there is no CPU fallback — if libptamd.so is missing or a HIP call fails, these functions
+raise.  torch is used (by ptamd.dist and bench.py) for device buffers, streams and
+torch.distributed only.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(PKG_ROOT, "libptamd.so")
+
+PRIM_FLOATS = 84      # sizeof(PtPrimitive) / 4   (3 x 112-byte Vertex, include/mesh.h:21-37)
+TRI_FLOATS = 88       # sizeof(PtTriangle) / 4
+NODE_BYTES = 40       # sizeof(PtBVHNode)        (CudaBVHNode, include/CudaPrimitive.cuh:237-247)
+SPHERE_FLOATS = 16
+TILE = 8
+
+NODE_DTYPE = np.dtype([("bMin", "<f4", 3), ("bMax", "<f4", 3), ("childL", "<i4"), ("childR", "<i4"),
+                       ("primStart", "<i4"), ("primEnd", "<i4")])
+assert NODE_DTYPE.itemsize == NODE_BYTES
+
+
+class PtError(RuntimeError):
+    pass
+
+
+class PtCamera(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("forward", C.c_float * 3), ("up", C.c_float * 3), ("right", C.c_float * 3),
+                ("fovy_deg", C.c_float), ("aspect", C.c_float), ("W", C.c_int32), ("H", C.c_int32)]
+
+
+class PtParams(C.Structure):
+    _fields_ = [("passes", C.c_int32), ("spp_per_pass", C.c_int32), ("max_bounce", C.c_int32), ("rr_bounce", C.c_int32),
+                ("rr_floor", C.c_float), ("max_refract", C.c_int32), ("first_pass", C.c_int32),
+                ("rank", C.c_int32), ("world", C.c_int32)]
+
+
+_lib = None
+
+# every symbol include/pt_api.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+API = [
+    ("pt_params_default", None, [C.POINTER(PtParams)]),
+    ("pt_last_error", C.c_char_p, []),
+    ("pt_version", C.c_char_p, []),
+    ("pt_bvh_build_sah", C.c_int, [_P, C.c_int32, C.POINTER(_P)]),
+    ("pt_bvh_free", None, [_P]),
+    ("pt_bvh_num_nodes", C.c_int32, [_P]),
+    ("pt_bvh_num_tris", C.c_int32, [_P]),
+    ("pt_bvh_max_depth", C.c_int32, [_P]),
+    ("pt_bvh_nodes", _P, [_P]),
+    ("pt_bvh_tris", _P, [_P]),
+    ("pt_scene_create", C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    ("pt_scene_destroy", None, [_P]),
+    ("pt_scene_num_lights", C.c_int32, [_P]),
+    ("pt_scene_device_bytes", C.c_int64, [_P]),
+    ("pt_tiles_floats", C.c_int64, [C.POINTER(PtCamera), C.POINTER(PtParams)]),
+    ("pt_work_bytes", C.c_int64, [C.POINTER(PtCamera), C.POINTER(PtParams)]),
+    ("pt_render_tiles", C.c_int, [_P, C.POINTER(PtCamera), C.POINTER(PtParams), _P, _P, _P]),
+    ("pt_untile", C.c_int, [_P, C.POINTER(PtCamera), C.c_int32, _P, _P]),
+    ("pt_render", C.c_int, [_P, C.POINTER(PtCamera), C.POINTER(PtParams), _P]),
+    ("pt_last_render_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
+    ("pt_tonemap_u8", C.c_int, [_P, C.c_int64, C.c_int32, _P]),
+    ("pt_write_png", C.c_int, [C.c_char_p, _P, C.c_int32, C.c_int32, C.c_int32]),
+    ("pt_camera_basis", None, [C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3)]),
+    ("pt_scene_gen", C.c_int32, [C.c_int32, C.c_int32, _P, C.c_int32]),
+    ("pt_load_obj", C.c_int32, [C.c_char_p, C.c_float, C.POINTER(C.c_float * 3), _P, C.c_int32]),
+    ("pt_dbg_raycast", C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    ("pt_dbg_bxdf", C.c_int, [C.c_int32, C.c_int32, _P, C.c_int32, _P]),
+    ("pt_dbg_rng", C.c_int, [C.c_int32, C.c_uint64, C.c_int32, _P, _P]),
+    ("pt_dbg_math", C.c_int, [C.c_int32, _P, C.c_int32, _P]),
+    ("pt_last_counters", C.c_int, [_P, _P]),
+    ("pt_enable_counters", C.c_int, [_P, C.c_int32]),
+]
+
+
+def lib():
+    """Load libptamd.so (built by __graft_entry__.build() / `make -C pathtrace-on-cuda_amd`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PtError(f"{LIB_PATH} is missing: build it with `make -C {PKG_ROOT}` "
+                          "(there is no CPU fallback for the render path)")
+        l = C.CDLL(LIB_PATH)
+        for name, res, args in API:
+            fn = getattr(l, name)       # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise PtError(f"{what} failed ({rc}): {lib().pt_last_error().decode()}")
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_params(**kw):
+    p = PtParams()
+    lib().pt_params_default(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def camera_basis(rot_deg=(0.0, 90.0, 0.0)):
+    r = (C.c_float * 3)(*rot_deg)
+    f, u, rt = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)()
+    lib().pt_camera_basis(C.byref(r), C.byref(f), C.byref(u), C.byref(rt))
+    return np.array(f[:], np.float32), np.array(u[:], np.float32), np.array(rt[:], np.float32)
+
+
+def make_camera(W, H, pos=(0.0, 20.0, 60.0), rot_deg=(0.0, 90.0, 0.0), fovy_deg=45.0):
+    """The reference app's camera: Renderer ctor puts it at (0,20,60) with rotation (0,90,0)
+    (srcs/renderer.cpp:28-30); SetScreenSize sets aspect = W/H (srcs/renderer.cpp:47-53)."""
+    f, u, r = camera_basis(rot_deg)
+    c = PtCamera()
+    c.pos[:] = pos
+    c.forward[:] = f.tolist()
+    c.up[:] = u.tolist()
+    c.right[:] = r.tolist()
+    c.fovy_deg = fovy_deg
+    c.aspect = np.float32(W) / np.float32(H)
+    c.W, c.H = W, H
+    return c
+
+
+def gen_scene(kind, lat_lon=187):
+    """Procedural scene as a (n, 84) float32 array of reference `Primitive` records."""
+    n = lib().pt_scene_gen(kind, lat_lon, None, 0)
+    if n < 0:
+        _check(n, "pt_scene_gen")
+    prims = np.zeros((n, PRIM_FLOATS), np.float32)
+    n2 = lib().pt_scene_gen(kind, lat_lon, _ptr(prims), n)
+    assert n2 == n
+    return prims
+
+
+def build_bvh(prims):
+    """SAH build + flatten.  Returns (nodes[NODE_DTYPE], tris float32 (n,88), max_depth)."""
+    prims = np.ascontiguousarray(prims, np.float32)
+    assert prims.ndim == 2 and prims.shape[1] == PRIM_FLOATS
+    h = C.c_void_p()
+    _check(lib().pt_bvh_build_sah(_ptr(prims), prims.shape[0], C.byref(h)), "pt_bvh_build_sah")
+    try:
+        nn, nt = lib().pt_bvh_num_nodes(h), lib().pt_bvh_num_tris(h)
+        nodes = np.frombuffer(C.string_at(lib().pt_bvh_nodes(h), nn * NODE_BYTES), NODE_DTYPE).copy()
+        tris = np.frombuffer(C.string_at(lib().pt_bvh_tris(h), nt * TRI_FLOATS * 4), np.float32).reshape(nt, TRI_FLOATS).copy()
+        depth = lib().pt_bvh_max_depth(h)
+    finally:
+        lib().pt_bvh_free(h)
+    return nodes, tris, depth
+
+
+def make_sphere(center, rad, emittance=(0, 0, 0), albedo=(1, 1, 1), specular=(0.04, 0.04, 0.04),
+                opacity=1.0, roughness=0.2, metallic=1.0):
+    """One PtSphere record (16 float32): center rad | emittance albedo specular opacity roughness metallic."""
+    return np.array([*center, rad, *emittance, *albedo, *specular, opacity, roughness, metallic], np.float32)
+
+
+def tonemap_u8(raw_rgb, sample_cnt):
+    raw = np.ascontiguousarray(raw_rgb, np.float32)
+    out = np.zeros(raw.shape, np.uint8)
+    _check(lib().pt_tonemap_u8(_ptr(raw), raw.size // 3, sample_cnt, _ptr(out)), "pt_tonemap_u8")
+    return out
+
+
+def write_png(path, rgb8):
+    a = np.ascontiguousarray(rgb8, np.uint8)
+    H, W, ch = a.shape
+    _check(lib().pt_write_png(path.encode(), _ptr(a), W, H, ch), "pt_write_png")
+
+
+class Scene:
+    """An uploaded scene (PtScene): HBM-resident wide-node BVH, triangle records, lights."""
+
+    def __init__(self, nodes, tris, spheres=None, device=0):
+        nodes = np.ascontiguousarray(nodes)
+        tris = np.ascontiguousarray(tris, np.float32)
+        assert nodes.dtype == NODE_DTYPE and tris.ndim == 2 and tris.shape[1] == TRI_FLOATS
+        if spheres is None:
+            spheres = np.zeros((0, SPHERE_FLOATS), np.float32)
+        spheres = np.ascontiguousarray(spheres, np.float32).reshape(-1, SPHERE_FLOATS)
+        self.device = device
+        self._h = C.c_void_p()
+        _check(lib().pt_scene_create(_ptr(nodes), nodes.shape[0], _ptr(tris), tris.shape[0],
+                                     _ptr(spheres) if spheres.shape[0] else None, spheres.shape[0], device, C.byref(self._h)),
+               "pt_scene_create")
+
+    @classmethod
+    def from_prims(cls, prims, spheres=None, device=0):
+        nodes, tris, _ = build_bvh(prims)
+        return cls(nodes, tris, spheres, device)
+
+    def close(self):
+        if self._h:
+            lib().pt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def num_lights(self):
+        return lib().pt_scene_num_lights(self._h)
+
+    @property
+    def device_bytes(self):
+        return lib().pt_scene_device_bytes(self._h)
+
+    def render(self, cam, prm):
+        """Whole frame, synchronous; returns (H, W, 3) float32 accumulated radiance."""
+        out = np.zeros((cam.H, cam.W, 3), np.float32)
+        _check(lib().pt_render(self._h, C.byref(cam), C.byref(prm), _ptr(out)), "pt_render")
+        return out
+
+    def render_tiles(self, cam, prm, d_tiles_ptr, d_work_ptr, stream_ptr=0):
+        """Asynchronous device-resident render of this rank's tiles (raw device pointers)."""
+        _check(lib().pt_render_tiles(self._h, C.byref(cam), C.byref(prm), C.c_void_p(d_tiles_ptr), C.c_void_p(d_work_ptr),
+                                     C.c_void_p(stream_ptr)), "pt_render_tiles")
+
+    def last_render_ms(self):
+        ms = C.c_float()
+        _check(lib().pt_last_render_ms(self._h, C.byref(ms)), "pt_last_render_ms")
+        return ms.value
+
+    def enable_counters(self, on=True):
+        _check(lib().pt_enable_counters(self._h, 1 if on else 0), "pt_enable_counters")
+
+    def counters(self):
+        out = np.zeros(8, np.int64)
+        _check(lib().pt_last_counters(self._h, _ptr(out)), "pt_last_counters")
+        return out
+
+    def raycast(self, rays8):
+        rays8 = np.ascontiguousarray(rays8, np.float32).reshape(-1, 8)
+        n = rays8.shape[0]
+        hits = np.zeros((n, 29), np.float32)
+        prim = np.zeros(n, np.int32)
+        _check(lib().pt_dbg_raycast(self._h, _ptr(rays8), n, _ptr(hits), _ptr(prim)), "pt_dbg_raycast")
+        return hits, prim
+
+
+def tiles_floats(cam, prm):
+    n = lib().pt_tiles_floats(C.byref(cam), C.byref(prm))
+    if n < 0:
+        raise PtError(lib().pt_last_error().decode())
+    return n
+
+
+def work_bytes(cam, prm):
+    n = lib().pt_work_bytes(C.byref(cam), C.byref(prm))
+    if n < 0:
+        raise PtError(lib().pt_last_error().decode())
+    return n
+
+
+def untile(d_gathered_ptr, cam, world, d_frame_ptr, stream_ptr=0):
+    _check(lib().pt_untile(C.c_void_p(d_gathered_ptr), C.byref(cam), world, C.c_void_p(d_frame_ptr), C.c_void_p(stream_ptr)), "pt_untile")
+
+
+def dbg_bxdf(lobe, in28, device=0):
+    in28 = np.ascontiguousarray(in28, np.float32).reshape(-1, 28)
+    out = np.zeros((in28.shape[0], 12), np.float32)
+    _check(lib().pt_dbg_bxdf(device, lobe, _ptr(in28), in28.shape[0], _ptr(out)), "pt_dbg_bxdf")
+    return out
+
+
+def dbg_rng(seed, n, device=0):
+    raw = np.zeros(n, np.uint32)
+    uni = np.zeros(n, np.float32)
+    _check(lib().pt_dbg_rng(device, seed, n, _ptr(raw), _ptr(uni)), "pt_dbg_rng")
+    return raw, uni
+
+
+def dbg_math(x, device=0):
+    x = np.ascontiguousarray(x, np.float32).ravel()
+    out = np.zeros((x.size, 8), np.float32)
+    _check(lib().pt_dbg_math(device, _ptr(x), x.size, _ptr(out)), "pt_dbg_math")
+    return out
