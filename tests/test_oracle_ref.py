@@ -1,0 +1,77 @@
+"""Oracle vs the REAL reference (partial build oracle/_ref/ptref): committed golden
+vectors always; live cross-check on fresh seeded inputs where the binary is present."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import ptamd
+from scenes_util import jittered_grid, random_rays10, random_spheres16, random_tris48
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("name", ["ref_bvh_cornell", "ref_bvh_grid5000"])
+def test_bvh_flatten_matches_reference_golden(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    nodes, tris, _ = O.bvh_build(g["prims"])
+    assert nodes.tobytes() == g["nodes"].tobytes()          # CudaBVH, byte for byte
+    assert np.array_equal(bits(tris), bits(g["tris"]))      # CudaPrims after Triangle::Copy
+
+
+def test_bvh_hashes_of_config_scenes(golden_dir):
+    h = json.load(open(os.path.join(golden_dir, "ref_bvh_hashes.json")))
+    for name in ("standin24", "standin187"):                # 4x187 (2.5 s) is covered by the live test below
+        e = h[name]
+        prims = ptamd.gen_scene(e["kind"], e["lat_lon"])
+        assert prims.shape[0] == e["n_prims"] and sha(prims) == e["prims_sha256"]   # geometry generator is stable
+        nodes, tris, _ = O.bvh_build(prims)
+        assert nodes.size // 40 == e["n_nodes"]
+        assert sha(nodes) == e["nodes_sha256"] and sha(tris) == e["tris_sha256"]
+
+
+def test_triangle_hit_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ref_trihit.npz"))
+    out = O.tri_hit(g["tris48"], g["rays10"])
+    assert (g["hits"][:, 0] > 0).sum() > 1000               # the table does exercise hits
+    assert np.array_equal(bits(out), bits(g["hits"]))
+
+
+def test_sphere_hit_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ref_sphit.npz"))
+    out = O.sphere_hit(g["sph16"], g["rays10"])
+    assert (g["hits"][:, 0] > 0).sum() > 200
+    assert np.array_equal(bits(out), bits(g["hits"]))
+
+
+def test_vec3_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ref_vecmath.npz"))
+    assert np.array_equal(bits(O.vecmath(g["in7"])), bits(g["out21"]))
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref/ptref not built (reference tree absent)")
+def test_live_against_reference_binary():
+    rs = np.random.RandomState(99)
+    grid = jittered_grid(20, 25, rs)
+    n_r, t_r = O.ref_bvh(grid)
+    n_o, t_o, _ = O.bvh_build(grid)
+    assert n_r.tobytes() == n_o.tobytes() and np.array_equal(bits(t_r), bits(t_o))
+    tris = random_tris48(32, rs)
+    rays = random_rays10(2000, 32, tris, rs)
+    assert np.array_equal(bits(O.ref_tri_hit(tris, rays)), bits(O.tri_hit(tris, rays)))
+    sph = random_spheres16(5, rs)
+    rays = random_rays10(1000, 5, None, rs, spheres=sph)
+    assert np.array_equal(bits(O.ref_sphere_hit(sph, rays)), bits(O.sphere_hit(sph, rays)))
+    prims = ptamd.gen_scene(2, 187)                          # 278k triangles, deep tree
+    n_r, t_r = O.ref_bvh(prims)
+    n_o, t_o, _ = O.bvh_build(prims)
+    assert n_r.tobytes() == n_o.tobytes() and np.array_equal(bits(t_r), bits(t_o))
