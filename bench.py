@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s (pixels x spp) of the radiance integrator on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+Workload = BASELINE.json configs[2], the configuration the metric is quoted on: Cornell room
++ 69,564-triangle "bunny" stand-in with the specular-reflection BRDF (69,576 triangles,
+45,075 BVH nodes), 1920x1080, NEE on, the reference's camera.  Scene data is synthetic
+(the reference ships no assets).
+
+A STEP is one full-frame PASS of the hot path: every pixel of the frame runs
+`spp_per_pass` = 256 camera paths (2048 spp = 8 passes x 256, as SURVEY.md §8d maps config 3).
+With N GPUs the frame's 8x8 tiles are dealt round-robin to the ranks (total work fixed ->
+"strong" scaling); after the K timed steps the finished tiles are gathered to rank 0 with
+ONE collective (RCCL over xGMI) and de-interleaved — that exchange is inside the timed
+region.  value = W*H*spp_per_pass*K / seconds / 1e6, whole job, inputs resident in HBM.
+
+Also on the JSON line:
+  roofline     — for the dominant kernel (render_units): achieved = algorithmic bytes per
+                 launch / average launch duration (HIP events on the launch stream), against
+                 the 8 TB/s HBM peak.  Algorithmic bytes per sample are those of the
+                 REFERENCE's traversal (40 B per node fetched + 36 B per
+                 triangle test + 156 B per ray with an accepted hit, + 24 B/spp_per_pass),
+                 counted by the instrumented CPU oracle on this same scene.
+  cpu_baseline — the CPU oracle (restatement of the reference's algorithm) timed on this
+                 host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "pathtrace-on-cuda_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+W, H = 1920, 1080
+SPP_PER_PASS = 256
+LAT_LON = 187
+
+
+def algorithmic_bytes_per_sample(cnt, spp_per_pass):
+    """sum over rays of 40*nodes + 36*tris + 156*[accepted hit], per camera
+    path, + 24/spp_per_pass (accumulator read+write), with the reference algorithm's counts."""
+    rays, nodes, tris, _, hits, paths = (float(x) for x in cnt[:6])
+    return (40.0 * nodes + 36.0 * tris + 156.0 * hits) / paths + 24.0 / spp_per_pass
+
+
+def cpu_baseline(nodes, tris, ncores):
+    """Oracle timed on the host: the same 1080p frame and scene, 1 pass x 1 spp, on a window
+    sized for ~10-30 s of CPU work.  Returns (dict, counters)."""
+    import numpy as np
+    import oracle_lib as O
+    O.set_libm(1)
+    sc = O.Scene(nodes.tobytes(), tris)
+    # calibrate on 8 rows, then size the timed window
+    cam = O.make_camera(W, H)
+    y0 = H // 2 - 4
+    t0 = time.time()
+    sc.render(cam, O.make_params(W, H, 1, 1, window=(0, y0, W, y0 + 8)), ncores)
+    per_row = (time.time() - t0) / 8
+    rows = int(max(16, min(H, 15.0 / max(per_row, 1e-6))))
+    rows -= rows % 8
+    ya = (H - rows) // 2
+    t0 = time.time()
+    _, cnt = sc.render(cam, O.make_params(W, H, 1, 1, window=(0, ya, W, ya + rows)), ncores)
+    dt = time.time() - t0
+    n = int(cnt[5])
+    return ({"value": n / dt / 1e6, "unit": "Msamples/s", "cores": ncores, "kind": "port",
+             "sample": f"same scene and 1920x1080 camera, rows {ya}..{ya + rows} x 1920 px, 1 pass x 1 spp "
+                       f"({n} paths, {dt:.1f} s, oracle/pt_oracle.cpp with {ncores} threads)"}, cnt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=SPP_PER_PASS, help="spp per pass (non-default values are for profiling only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import ptamd
+    from ptamd.dist import TileRenderer, gather_tiles
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the render path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- scene (host): every rank builds and uploads its own replica (no collective needed) ----
+    t0 = time.time()
+    prims = ptamd.gen_scene(1, LAT_LON)
+    nodes, tris, depth = ptamd.build_bvh(prims)
+    t_build = time.time() - t0
+    scene = ptamd.Scene(nodes, tris, device=local_rank)
+    cam = ptamd.make_camera(W, H)
+
+    def params(first_pass):
+        return ptamd.default_params(passes=1, spp_per_pass=args.spp, first_pass=first_pass, rank=rank, world=world)
+
+    tr = TileRenderer(scene, cam, params(0), dev)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    step = 0
+    for _ in range(args.warmup):
+        tr.prm = params(step % 8); tr.render(); step += 1
+    if world > 1:   # warm the collective once as well
+        gather_tiles(tr.tiles, rank, world)
+    barrier()
+    scene.render_timings(reset=True)
+    acc = torch.zeros_like(tr.tiles)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.prm = params(step % 8); tr.render(); step += 1
+        acc.add_(tr.tiles)                                   # image += mean(pass), srcs/pathtracer.cu:81
+    gathered = gather_tiles(acc, rank, world)                # the single exchange step
+    if rank == 0:
+        frame = tr.assemble(gathered, world)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms = scene.render_timings(reset=True)
+
+    if rank == 0:
+        samples = float(W) * H * args.spp * args.steps
+        value = samples / dt / 1e6
+        out = {
+            "metric": "Msamples/sec (pixels x spp) at 1080p on bunny scene", "value": value, "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: Cornell room + 69,564-tri bunny stand-in (specular reflection BRDF), "
+                                   "1920x1080, NEE on; step = one full-frame pass of %d spp" % args.spp,
+                       "triangles": int(tris.shape[0]), "bvh_nodes": int(nodes.shape[0]), "bvh_depth": int(depth),
+                       "spp_per_pass": args.spp, "parallelism": f"tile-split x{world}, one gather",
+                       "host_bvh_build_s": round(t_build, 3)},
+        }
+        cpu, cnt = (None, None)
+        if world == 1 and not args.no_cpu_baseline:
+            ncores = len(os.sched_getaffinity(0))
+            cpu, cnt = cpu_baseline(nodes, tris, ncores)
+        if cnt is not None:
+            bps = algorithmic_bytes_per_sample(cnt, args.spp)
+        else:
+            bps = 63490.0 + 24.0 / args.spp      # oracle counters of this scene at 320x180 (BASELINE.md §2 method)
+        k_ms = float(np.mean(kern_ms)) if len(kern_ms) else dt * 1e3 / args.steps
+        launch_samples = float(W) * H * args.spp / world
+        achieved = launch_samples * bps / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tp):
+            try:
+                tj = json.load(open(tp))
+                if tj.get("spp_per_pass") == args.spp and tj.get("n_gpus", 1) == world:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "kernel": "render_units", "kernel_ms_avg": k_ms, "launches_timed": int(len(kern_ms)),
+                           "algorithmic_bytes_per_sample": bps}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        # a cheap sanity guard on the timed output (not a parity test): finite, plausible brightness
+        m = float(frame.mean().item())
+        if not (0.05 < m < 5.0) or not bool(torch.isfinite(frame).all().item()):
+            raise SystemExit(f"bench output implausible (mean {m})")
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -164,6 +164,11 @@ PT_API int  pt_render(PtScene* s, const PtCamera* cam, const PtParams* prm, floa
 /* Duration of the most recent pt_render_tiles launch sequence on this scene, measured with
  * HIP events on the stream it was launched on (ms), and the kernel's own work counters. */
 PT_API int  pt_last_render_ms(PtScene* s, float* ms);
+/* Durations (ms) of the most recent render_units launches on this scene (up to 64, oldest
+ * first), each measured with a HIP event pair recorded on the launch stream around that
+ * kernel only.  Returns the count written (<= cap) or a negative PtStatus; reset != 0 clears
+ * the history.  Blocks until those launches have finished. */
+PT_API int  pt_render_timings(PtScene* s, float* ms_out, int32_t cap, int32_t reset);
 
 /* ----------------------------------------------------------------------------------
  * (a12,a13) Output + camera helpers (host).

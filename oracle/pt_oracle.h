@@ -60,6 +60,10 @@ typedef struct {
  * rounded float results obtained through double precision (the pinned contract the HIP
  * kernel is held to).  Returns the previous mode. */
 int  o_set_libm(int mode);
+/* Dev aid (tools/trav_lab): log every ray RayCast sees (org dir tmax, 7 f each) during
+ * single-threaded o_render calls.  Pass NULL to stop. */
+void o_set_raylog(float* buf7, int cap);
+int  o_raylog_count(void);
 
 void o_rng(uint64_t seed, int n, uint32_t* raw_out, float* uniform_out);
 

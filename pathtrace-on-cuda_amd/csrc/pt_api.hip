@@ -50,8 +50,10 @@ struct PtScene {
     int max_depth = 0;
     int num_cus = 256;
     bool count_next = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    // ring of HIP event pairs, one pair per render_units launch (pt_render_timings)
+    static constexpr int kEvRing = 64;
+    hipEvent_t ev[kEvRing][2] = {};
+    int ev_count = 0;        // launches recorded since the last pt_render_timings(reset)
 };
 
 static int upload(void** dptr, const void* h, size_t bytes, int64_t& total)
@@ -215,8 +217,7 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     HIPCHK(hipMalloc((void**)&sc->d_unit_counter, 64));
     HIPCHK(hipMalloc(&sc->d_counters, 64));
     HIPCHK(hipMemset(sc->d_counters, 0, 64));
-    HIPCHK(hipEventCreate(&sc->ev0));
-    HIPCHK(hipEventCreate(&sc->ev1));
+    for (int i = 0; i < PtScene::kEvRing; i++) { HIPCHK(hipEventCreate(&sc->ev[i][0])); HIPCHK(hipEventCreate(&sc->ev[i][1])); }
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     sc->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -234,8 +235,7 @@ void pt_scene_destroy(PtScene* s)
     (void)hipSetDevice(s->device);
     void* p[] = {s->d_nodes, s->d_tri, s->d_shade, s->d_mats, s->d_lights, s->d_spheres, s->d_unit_counter, s->d_counters};
     for (void* q : p) if (q) (void)hipFree(q);
-    if (s->ev0) (void)hipEventDestroy(s->ev0);
-    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    for (int i = 0; i < PtScene::kEvRing; i++) for (int j = 0; j < 2; j++) if (s->ev[i][j]) (void)hipEventDestroy(s->ev[i][j]);
     delete s;
 }
 
@@ -300,7 +300,6 @@ int pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm, float*
 
     hipStream_t stream = (hipStream_t)hip_stream;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipEventRecord(s->ev0, stream));
     HIPCHK(hipMemsetAsync(s->d_unit_counter, 0, 4, stream));
     if (s->count_next) HIPCHK(hipMemsetAsync(s->d_counters, 0, 64, stream));
     // persistent grid: 4 blocks of 4 waves per CU (16 waves/CU; register- and LDS-feasible), never more blocks than units need
@@ -308,10 +307,13 @@ int pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm, float*
     const int need = (d.n_units + ptd::kWavesPerBlock - 1) / ptd::kWavesPerBlock;
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
+    // events bracket exactly the render_units launch (the dominant kernel), on the launch stream
+    const int slot = s->ev_count % PtScene::kEvRing;
+    HIPCHK(hipEventRecord(s->ev[slot][0], stream));
     HIPCHK(ptk_render_units(&s->dev, &c, &d, (float*)d_work, s->d_unit_counter, s->d_counters, blocks, s->count_next ? 1 : 0, stream));
+    HIPCHK(hipEventRecord(s->ev[slot][1], stream));
+    s->ev_count++;
     HIPCHK(ptk_sum_passes((const float*)d_work, d.passes, (long long)d.n_tiles_local * ptd::kTilePixels * 3, d_tiles, stream));
-    HIPCHK(hipEventRecord(s->ev1, stream));
-    s->timed = true;
     return PT_OK;
 }
 
@@ -348,11 +350,27 @@ int pt_render(PtScene* s, const PtCamera* cam, const PtParams* prm, float* h_acc
 
 int pt_last_render_ms(PtScene* s, float* ms)
 {
-    if (!s || !ms || !s->timed) { pt_set_error("pt_last_render_ms: nothing rendered yet"); return PT_ERR_INVALID; }
+    if (!s || !ms || s->ev_count < 1) { pt_set_error("pt_last_render_ms: nothing rendered yet"); return PT_ERR_INVALID; }
+    const int slot = (s->ev_count - 1) % PtScene::kEvRing;
     HIPCHK(hipSetDevice(s->device));
-    HIPCHK(hipEventSynchronize(s->ev1));
-    HIPCHK(hipEventElapsedTime(ms, s->ev0, s->ev1));
+    HIPCHK(hipEventSynchronize(s->ev[slot][1]));
+    HIPCHK(hipEventElapsedTime(ms, s->ev[slot][0], s->ev[slot][1]));
     return PT_OK;
+}
+
+int pt_render_timings(PtScene* s, float* ms_out, int32_t cap, int32_t reset)
+{
+    if (!s) { pt_set_error("pt_render_timings: NULL scene"); return PT_ERR_INVALID; }
+    int n = s->ev_count < PtScene::kEvRing ? s->ev_count : PtScene::kEvRing;
+    if (n > cap) n = cap;
+    HIPCHK(hipSetDevice(s->device));
+    for (int i = 0; i < n; i++) {
+        const int slot = (s->ev_count - n + i) % PtScene::kEvRing;
+        HIPCHK(hipEventSynchronize(s->ev[slot][1]));
+        HIPCHK(hipEventElapsedTime(&ms_out[i], s->ev[slot][0], s->ev[slot][1]));
+    }
+    if (reset) s->ev_count = 0;
+    return n;
 }
 
 int pt_last_counters(PtScene* s, int64_t* out8)

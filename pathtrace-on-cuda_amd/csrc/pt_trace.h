@@ -24,9 +24,10 @@ namespace ptd {
 
 struct TraceStats { uint32_t nodes, tris, spheres; };
 
-// Reference slab arithmetic for one box.  Returns the scaled entry distance in tn.
+// Reference slab arithmetic for one box (non-degenerate rays).  Returns the scaled entry
+// distance in tn.  `cullB` is the closest hit so far in the same scaled units, with slack.
 PT_DEV bool box_test(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz,
-                     const f3& org, const f3& invD, float cullB, bool degenerate, float& tn)
+                     const f3& org, const f3& invD, float cullB, float& tn)
 {
     float x1 = (bminx - org.x) * invD.x, x2 = (bmaxx - org.x) * invD.x;
     float y1 = (bminy - org.y) * invD.y, y2 = (bmaxy - org.y) * invD.y;
@@ -37,10 +38,40 @@ PT_DEV bool box_test(float bminx, float bminy, float bminz, float bmaxx, float b
     tn = __builtin_fmaxf(tzmin, __builtin_fmaxf(tymin, __builtin_fmaxf(txmin, 0.f)));
     float tf = __builtin_fminf(tzmax, __builtin_fminf(tymax, txmax));
     tf *= 1.00000024f;
-    // A ray with a zero / non-finite direction component makes the reference's normalised
-    // inverse direction NaN/0 and its test accept every box (CudaVector.cuh:226-234 select
-    // semantics); `degenerate` reproduces that.
-    return degenerate | ((tn <= tf) & (tn <= cullB));
+    return (tn <= tf) & (tn <= cullB);
+}
+
+// Degenerate rays: a direction component that is exactly 0 (or whose reciprocal overflows)
+// makes the reference's normalised inverse direction (NaN, 0, 0)-like, and with its
+// select-style max/min (CudaVector.cuh:226-234) its test then ACCEPTS EVERY BOX — the
+// reference brute-forces all triangles for such rays (in the Cornell scenes: every NEE ray
+// cast from a point on the light to another point on the light, 0.25 % of all rays, which is
+// where ~95 % of the reference's triangle tests go).  The result it returns is simply the
+// closest triangle that passes Triangle::hit.  This test finds the same triangles with a
+// geometrically correct slab test that is padded by 2^-10 relative — three orders of
+// magnitude above float rounding — so no triangle that Triangle::hit can accept is missed.
+// tn / cullB are in true (un-scaled) ray units here.
+PT_DEV bool box_test_robust(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz,
+                            const f3& org, const f3& dir, const f3& inv, float cullB, float& tn)
+{
+    float lo = 0.f, hi = __builtin_inff();
+    bool ok = true;
+    const float kPad = 0.0009765625f;
+#define PT_AXIS(c, mn, mx)                                                                               \
+    if (dir.c != 0.f && __builtin_fabsf(inv.c) < __builtin_inff()) {                                     \
+        const float a = (mn - org.c) * inv.c, b = (mx - org.c) * inv.c;                                  \
+        lo = __builtin_fmaxf(lo, __builtin_fminf(a, b));                                                 \
+        hi = __builtin_fminf(hi, __builtin_fmaxf(a, b));                                                 \
+    } else {                                                                                             \
+        const float pad = kPad * __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(mn), __builtin_fabsf(mx)), __builtin_fabsf(org.c)) + 1e-30f; \
+        ok = ok & (org.c >= mn - pad) & (org.c <= mx + pad);                                             \
+    }
+    PT_AXIS(x, bminx, bmaxx)
+    PT_AXIS(y, bminy, bmaxy)
+    PT_AXIS(z, bminz, bmaxz)
+#undef PT_AXIS
+    tn = lo;
+    return ok & (lo * (1.f - kPad) <= hi * (1.f + kPad) + 1e-30f) & (lo <= cullB);
 }
 
 // Moeller-Trumbore with the reference's back-face cull and test order,
@@ -94,7 +125,8 @@ PT_DEV int trace_closest(const DevScene& sc, const f3& org, const f3& dir, float
     const float L = __builtin_sqrtf(inv.x * inv.x + inv.y * inv.y + inv.z * inv.z);
     const f3 invD = inv / L;                                                 // Normalize(inv(dir)), :70
     const bool degenerate = !(L < __builtin_inff());
-    const float kcull = 1.0078125f / L;     // un-scales the reference's scaled entry distance, +2^-7 slack
+    // un-scales the reference's scaled entry distance (degenerate rays work un-scaled), +2^-7 slack
+    const float kcull = degenerate ? 1.0078125f : 1.0078125f / L;
     bestT = tmax;
     int bestPrim = -1;
     float cullB = bestT * kcull;
@@ -108,8 +140,14 @@ PT_DEV int trace_closest(const DevScene& sc, const f3& org, const f3& dir, float
         const float4 q3 = sc.nodes[4 * cur + 3];
         if (COUNT) st.nodes++;
         float tnL, tnR;
-        bool okL = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, org, invD, cullB, degenerate, tnL);
-        bool okR = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, org, invD, cullB, degenerate, tnR);
+        bool okL, okR;
+        if (!degenerate) {
+            okL = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, org, invD, cullB, tnL);
+            okR = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, org, invD, cullB, tnR);
+        } else {
+            okL = box_test_robust(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, org, dir, inv, cullB, tnL);
+            okR = box_test_robust(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, org, dir, inv, cullB, tnR);
+        }
         const int refL = __float_as_int(q3.x), refR = __float_as_int(q3.y);
 
         if (okL && refL < 0) {
@@ -120,7 +158,7 @@ PT_DEV int trace_closest(const DevScene& sc, const f3& org, const f3& dir, float
         }
         if (okR && refR < 0) {
             // re-check against the possibly tightened bound (result-neutral: skips boxes beyond the hit)
-            if (degenerate | (tnR <= cullB)) {
+            if (tnR <= cullB) {
                 const int code = ~refR, first = code >> 3, cnt = code & 7;
                 for (int k = 0; k < cnt; k++) { tri_test(sc.tri, first + k, org, dir, bestT, bestPrim); if (COUNT) st.tris++; }
                 cullB = bestT * kcull;

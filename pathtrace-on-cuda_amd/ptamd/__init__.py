@@ -66,6 +66,7 @@ API = [
     ("pt_untile", C.c_int, [_P, C.POINTER(PtCamera), C.c_int32, _P, _P]),
     ("pt_render", C.c_int, [_P, C.POINTER(PtCamera), C.POINTER(PtParams), _P]),
     ("pt_last_render_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
+    ("pt_render_timings", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     ("pt_tonemap_u8", C.c_int, [_P, C.c_int64, C.c_int32, _P]),
     ("pt_write_png", C.c_int, [C.c_char_p, _P, C.c_int32, C.c_int32, C.c_int32]),
     ("pt_camera_basis", None, [C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3)]),
@@ -240,6 +241,14 @@ class Scene:
         ms = C.c_float()
         _check(lib().pt_last_render_ms(self._h, C.byref(ms)), "pt_last_render_ms")
         return ms.value
+
+    def render_timings(self, reset=True):
+        """ms of each recent render_units launch (HIP events on the launch stream)."""
+        out = np.zeros(64, np.float32)
+        n = lib().pt_render_timings(self._h, _ptr(out), 64, 1 if reset else 0)
+        if n < 0:
+            _check(n, "pt_render_timings")
+        return out[:n].copy()
 
     def enable_counters(self, on=True):
         _check(lib().pt_enable_counters(self._h, 1 if on else 0), "pt_enable_counters")
