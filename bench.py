@@ -42,13 +42,6 @@ SPP_PER_PASS = 256
 LAT_LON = 187
 
 
-def algorithmic_bytes_per_sample(cnt, spp_per_pass):
-    """sum over rays of 40*nodes + 36*tris + 156*[accepted hit], per camera
-    path, + 24/spp_per_pass (accumulator read+write), with the reference algorithm's counts."""
-    rays, nodes, tris, _, hits, paths = (float(x) for x in cnt[:6])
-    return (40.0 * nodes + 36.0 * tris + 156.0 * hits) / paths + 24.0 / spp_per_pass
-
-
 def cpu_baseline(nodes, tris, ncores):
     """Oracle timed on the host: the same 1080p frame and scene, 1 pass x 1 spp, on a window
     sized for ~10-30 s of CPU work.  Returns (dict, counters)."""
@@ -161,12 +154,11 @@ def main():
         }
         cpu, cnt = (None, None)
         if world == 1 and not args.no_cpu_baseline:
-            ncores = len(os.sched_getaffinity(0))
+            ncores = min(len(os.sched_getaffinity(0)), 16)      # the box's CPU share for one GPU
             cpu, cnt = cpu_baseline(nodes, tris, ncores)
-        if cnt is not None:
-            bps = algorithmic_bytes_per_sample(cnt, args.spp)
-        else:
-            bps = 63490.0 + 24.0 / args.spp      # oracle counters of this scene at 320x180 (BASELINE.md §2 method)
+        # reference-algorithm counters of this exact workload (full 1080p frame), committed by oracle/gen_counters.py
+        tc = json.load(open(os.path.join(ROOT, "tests", "golden", "traversal_counters.json")))["config3_standin"]
+        bps = tc["bytes_per_sample_traversal"] + 24.0 / args.spp
         k_ms = float(np.mean(kern_ms)) if len(kern_ms) else dt * 1e3 / args.steps
         launch_samples = float(W) * H * args.spp / world
         achieved = launch_samples * bps / (k_ms * 1e-3) / 1e9
