@@ -209,7 +209,13 @@ PT_API int  pt_dbg_math(int32_t device, const float* in, int32_t n, float* out8)
  * [0] rays [1] node records fetched [2] triangle tests [3] sphere tests [4] rays with hit
  * [5] camera paths [6] loop trips of the wave scheduler [7] lane-trips with an active ray */
 PT_API int  pt_last_counters(PtScene* s, int64_t* out8);
-/* Run the counting build of the kernel on the next pt_render_tiles calls (slower). */
+/* Render path: 1 = queue-driven wavefront pipeline (default: traversal and shading are
+ * separate kernels, lanes refill from a ray queue), 0 = the one-kernel state machine.
+ * Both produce bit-identical frames.  Environment PTAMD_MODE overrides the default.
+ * pt_last_iterations: bounce iterations the pipeline needed for the last render. */
+PT_API int  pt_set_mode(PtScene* s, int32_t mode);
+PT_API int  pt_last_iterations(PtScene* s);
+/* Run the counting build of the kernel on the next pt_render_tiles calls (slower; mode 0). */
 PT_API int  pt_enable_counters(PtScene* s, int32_t on);
 
 #ifdef __cplusplus

@@ -25,6 +25,10 @@ hipError_t ptk_dbg_raycast(const ptd::DevScene*, const float*, int, float*, int*
 hipError_t ptk_dbg_bxdf(int, const float*, int, float*, hipStream_t);
 hipError_t ptk_dbg_rng(unsigned long long, int, uint32_t*, float*, hipStream_t);
 hipError_t ptk_dbg_math(const float*, int, float*, hipStream_t);
+size_t ptk_wf_work_bytes(size_t nStreams, int traceBlocks);
+const float* ptk_wf_staging(void* work, size_t nStreams, int traceBlocks);
+hipError_t ptk_wf_render(const ptd::DevScene*, const ptd::DevCamera*, const ptd::DevParams*, void*, int, uint32_t*, hipStream_t,
+                         hipEvent_t, hipEvent_t, int*);
 }
 
 void pt_set_error(const char* fmt, ...);   // pt_host.cpp
@@ -50,6 +54,9 @@ struct PtScene {
     int max_depth = 0;
     int num_cus = 256;
     bool count_next = false;
+    int mode = 1;            // 1 = wavefront pipeline (default), 0 = one-kernel state machine
+    uint32_t* h_poll = nullptr;   // pinned, for the pipeline's live-stream count
+    int last_iters = 0;
     // ring of HIP event pairs, one pair per render_units launch (pt_render_timings)
     static constexpr int kEvRing = 64;
     hipEvent_t ev[kEvRing][2] = {};
@@ -218,6 +225,8 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     HIPCHK(hipMalloc(&sc->d_counters, 64));
     HIPCHK(hipMemset(sc->d_counters, 0, 64));
     for (int i = 0; i < PtScene::kEvRing; i++) { HIPCHK(hipEventCreate(&sc->ev[i][0])); HIPCHK(hipEventCreate(&sc->ev[i][1])); }
+    HIPCHK(hipHostMalloc((void**)&sc->h_poll, 64, hipHostMallocDefault));
+    if (const char* m = getenv("PTAMD_MODE")) sc->mode = atoi(m) ? 1 : 0;
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     sc->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -236,17 +245,24 @@ void pt_scene_destroy(PtScene* s)
     void* p[] = {s->d_nodes, s->d_tri, s->d_shade, s->d_mats, s->d_lights, s->d_spheres, s->d_unit_counter, s->d_counters};
     for (void* q : p) if (q) (void)hipFree(q);
     for (int i = 0; i < PtScene::kEvRing; i++) for (int j = 0; j < 2; j++) if (s->ev[i][j]) (void)hipEventDestroy(s->ev[i][j]);
+    if (s->h_poll) (void)hipHostFree(s->h_poll);
     delete s;
 }
 
 int32_t pt_scene_num_lights(const PtScene* s) { return s ? s->n_lights : 0; }
 int64_t pt_scene_device_bytes(const PtScene* s) { return s ? s->bytes : 0; }
 
+static const int kTraceBlocks = 2048;   // persistent grid of the traversal kernel: 256 CUs x 8 blocks of 4 waves
+
 // ---- geometry of the tile split --------------------------------------------------------
 static int fill_params(const PtCamera* cam, const PtParams* prm, ptd::DevParams& d)
 {
     if (!cam || !prm) { pt_set_error("NULL camera/params"); return PT_ERR_INVALID; }
     if (cam->W < 2 || cam->H < 2) { pt_set_error("frame %dx%d too small (W-1, H-1 divide, srcs/pathtracer.cu:35-36)", cam->W, cam->H); return PT_ERR_INVALID; }
+    if (prm->spp_per_pass > 65535 || prm->max_bounce > 255 || prm->max_refract < 0 || prm->max_refract > 250) {
+        pt_set_error("params out of range: spp_per_pass <= 65535, max_bounce <= 255, 0 <= max_refract <= 250");
+        return PT_ERR_INVALID;
+    }
     if (prm->passes < 1 || prm->spp_per_pass < 1 || prm->max_bounce < 1 || prm->world < 1 || prm->rank < 0 || prm->rank >= prm->world) {
         pt_set_error("bad params: passes=%d spp=%d max_bounce=%d rank=%d world=%d", prm->passes, prm->spp_per_pass, prm->max_bounce, prm->rank, prm->world);
         return PT_ERR_INVALID;
@@ -276,7 +292,9 @@ int64_t pt_work_bytes(const PtCamera* cam, const PtParams* prm)
 {
     ptd::DevParams d;
     if (fill_params(cam, prm, d)) return -1;
-    return (int64_t)d.n_tiles_local * ptd::kTilePixels * 3 * 4 * prm->passes;
+    const int64_t mega = (int64_t)d.n_tiles_local * ptd::kTilePixels * 3 * 4 * prm->passes;
+    const int64_t wave = (int64_t)ptk_wf_work_bytes((size_t)d.n_units * 64, kTraceBlocks);
+    return mega > wave ? mega : wave;
 }
 
 int pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm, float* d_tiles, void* d_work, void* hip_stream)
@@ -300,6 +318,17 @@ int pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm, float*
 
     hipStream_t stream = (hipStream_t)hip_stream;
     HIPCHK(hipSetDevice(s->device));
+    const int slot = s->ev_count % PtScene::kEvRing;
+    const long long perPass = (long long)d.n_tiles_local * ptd::kTilePixels * 3;
+    if (s->mode == 1 && !s->count_next) {
+        // queue-driven pipeline (pt_wavefront.hip); polls the live-stream count, so it returns once the render has drained
+        int iters = 0;
+        HIPCHK(ptk_wf_render(&s->dev, &c, &d, d_work, kTraceBlocks, s->h_poll, stream, s->ev[slot][0], s->ev[slot][1], &iters));
+        s->last_iters = iters;
+        s->ev_count++;
+        HIPCHK(ptk_sum_passes(ptk_wf_staging(d_work, (size_t)d.n_units * 64, kTraceBlocks), d.passes, perPass, d_tiles, stream));
+        return PT_OK;
+    }
     HIPCHK(hipMemsetAsync(s->d_unit_counter, 0, 4, stream));
     if (s->count_next) HIPCHK(hipMemsetAsync(s->d_counters, 0, 64, stream));
     // persistent grid: 4 blocks of 4 waves per CU (16 waves/CU; register- and LDS-feasible), never more blocks than units need
@@ -308,12 +337,11 @@ int pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm, float*
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
     // events bracket exactly the render_units launch (the dominant kernel), on the launch stream
-    const int slot = s->ev_count % PtScene::kEvRing;
     HIPCHK(hipEventRecord(s->ev[slot][0], stream));
     HIPCHK(ptk_render_units(&s->dev, &c, &d, (float*)d_work, s->d_unit_counter, s->d_counters, blocks, s->count_next ? 1 : 0, stream));
     HIPCHK(hipEventRecord(s->ev[slot][1], stream));
     s->ev_count++;
-    HIPCHK(ptk_sum_passes((const float*)d_work, d.passes, (long long)d.n_tiles_local * ptd::kTilePixels * 3, d_tiles, stream));
+    HIPCHK(ptk_sum_passes((const float*)d_work, d.passes, perPass, d_tiles, stream));
     return PT_OK;
 }
 
@@ -381,6 +409,8 @@ int pt_last_counters(PtScene* s, int64_t* out8)
     HIPCHK(hipMemcpy(out8, s->d_counters, 64, hipMemcpyDeviceToHost));
     return PT_OK;
 }
+PT_API int pt_set_mode(PtScene* s, int32_t mode) { if (!s || mode < 0 || mode > 1) { pt_set_error("pt_set_mode: bad argument"); return PT_ERR_INVALID; } s->mode = mode; return PT_OK; }
+PT_API int pt_last_iterations(PtScene* s) { return s ? s->last_iters : -1; }
 // Ask the next pt_render_tiles on this scene to run the counting build of the kernel.
 PT_API int pt_enable_counters(PtScene* s, int32_t on) { if (!s) return PT_ERR_INVALID; s->count_next = on != 0; return PT_OK; }
 

@@ -1,0 +1,498 @@
+// pt_wavefront.hip — the integrator as a queue-driven pipeline (the default render path).
+//
+// Why: the one-kernel state machine (pt_kernels.hip, kept as `mode 0`) is issue-bound at
+// ~11 % SIMD lane utilisation (profiles/r01_pmc_megakernel_v1.json): rays of very different
+// length share a wave, leaf code runs for a few lanes at a time, and the fat shading code
+// holds 190 VGPRs (2 waves/SIMD).  Here every (pixel, pass) is a *stream* whose state lives
+// in HBM as SoA float4 arrays; each iteration advances every live stream by one bounce:
+//
+//   wf_trace<PATH>    closest hits of all pending path rays      } lean kernel, 8 waves/SIMD,
+//   wf_trace<SHADOW>  visibility of all pending NEE shadow rays  } lanes refill from the queue
+//   wf_shade          apply NEE, shade the path hit, draw the bounce's random numbers, emit the
+//                     next shadow ray + path ray (or the next sample's camera ray), or retire
+//                     the stream and write its per-pass mean.
+//
+// The traversal kernel is persistent: a wave takes ray ids from a global queue in chunks and,
+// whenever >= 16 of its lanes have finished their ray, hands them new ones (ballot + mbcnt
+// compaction), so lanes do not idle for the longest ray of the wave.  Inside it the classic
+// while-while shape is used: all lanes walk interior nodes until each holds a leaf, then all
+// lanes test triangles.  Shadow rays stop at the first hit that is provably in front of the
+// sampled light point (result-neutral, see wf_trace).
+//
+// Per-stream arithmetic — order of random draws, every float operation — is exactly that of
+// render_units / the reference's GetColor_iter, so images are bit-identical across modes.
+#include <hip/hip_runtime.h>
+#include "pt_device.h"
+#include "pt_math.h"
+#include "pt_bxdf.h"
+#include "pt_trace.h"
+#include "pt_shade.h"
+
+namespace ptd {
+
+enum : uint32_t {
+    F_REFR = 1,      // bRefracted (loop-carried, Q8)
+    F_NEEOK = 2,     // !isnan(brdfcos) of the pending NEE term
+    F_SHADOW = 4,    // a shadow ray was traced for this stream: NEE term pending
+    F_PATH = 8,      // a path ray was traced for this stream
+    F_NEWPATH = 16,  // that path ray is the NEXT sample's camera ray: retire the old path first
+};
+
+struct WfCounters {      // one slot per iteration parity (3 rotating slots)
+    uint32_t nActive, nPath, nShadow, headPath, headShadow, pad[3];
+};
+
+struct WfBuf {
+    uint4* rng0;         // x0 x1 x2 x3
+    uint4* rng1;         // x4 d | samplesLeft<<16 | depth<<8 | refractCnt | flags
+    float4* weight;      // weight.xyz | cosA
+    float4* rad;         // radiance.xyz | denom
+    float4* pix;         // pixelColor.xyz
+    float4* dir0;        // camera ray direction of this pixel & pass
+    float4* wb;          // weight*brdfcos of the pending NEE term
+    float4* lp;          // sampled light point of the pending NEE term
+    float4* ray_o[2];    // [0] path, [1] shadow: org.xyz | tmax
+    float4* ray_d[2];    // dir.xyz
+    float2* hit[2];      // t | primitive index (int bits)
+    uint32_t* active[2]; // live stream ids, ping-pong
+    uint32_t* rq[2];     // ray queues (stream ids): [0] path, [1] shadow
+    WfCounters* cnt;     // [3]
+    float* staging;      // per-pass means, [stream][3]
+    int* ovf;            // traversal stack overflow (entries >= kWfLdsStack), [level][thread]
+};
+
+constexpr int kWfLdsStack = 16;      // stack entries per lane kept in LDS (4 KB / wave -> 8 waves/SIMD fit)
+constexpr int kWfOvfLevels = 32;     // further levels spill to global memory (never seen on the config scenes)
+constexpr int kWfChunk = 256;        // ray ids a wave takes from the global queue per atomic
+constexpr int kWfRefill = 16;        // refill lanes once this many are idle
+constexpr int kDone = (int)0x80000000;
+
+// wave-aggregated append of one id per participating lane
+PT_DEV void wave_append(bool emit, uint32_t id, uint32_t* counter, uint32_t* list)
+{
+    const unsigned long long m = __ballot(emit);
+    if (m == 0ull) return;
+    uint32_t base = 0;
+    const int lane = threadIdx.x & 63;
+    const int leader = __builtin_ctzll(m);
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
+    base = __shfl(base, leader);
+    if (emit) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = id;
+}
+
+// ---------------------------------------------------------------------------------------
+// wf_init: StartRender prologue for every stream (pathtracer.cu:70-74)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
+{
+    const uint32_t sid = blockIdx.x * 256u + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 16) { ((uint32_t*)&b.cnt[1])[threadIdx.x & 7] = 0; ((uint32_t*)&b.cnt[2])[threadIdx.x & 7] = 0; }
+    bool live = false;
+    if (sid < nStreams) {
+        const uint32_t unit = sid >> 6, lane = sid & 63;
+        const int pass_rel = (int)(unit / (uint32_t)prm.n_tiles_local);
+        const int lt = (int)(unit % (uint32_t)prm.n_tiles_local);
+        const int tile = lt * prm.world + prm.rank;
+        const int tx = tile % prm.tiles_x, ty = tile / prm.tiles_x;
+        const int px = tx * kTile + (int)(lane & 7), py = ty * kTile + (int)(lane >> 3);
+        const int pass = prm.first_pass + pass_rel;
+        live = (tile < prm.n_tiles_total) && (px < cam.W) && (py < cam.H);
+        if (live) {
+            const f3 camF(cam.forward[0], cam.forward[1], cam.forward[2]);
+            const f3 camU(cam.up[0], cam.up[1], cam.up[2]);
+            const f3 camR(cam.right[0], cam.right[1], cam.right[2]);
+            const int offset = py * cam.W + px;
+            Rng rng;
+            rng.init((uint64_t)(int64_t)(offset + pass * cam.W * cam.H));
+            const float u1 = rng.uniform();
+            const float u2 = rng.uniform();
+            const f3 offR = ((2.f * (((float)px + u1) / (float)(cam.W - 1) - 0.5f)) * cam.tan_half_fovx) * camR;
+            const f3 offU = ((-2.f * (((float)py + u2) / (float)(cam.H - 1) - 0.5f)) * cam.tan_half_fovy) * camU;
+            const f3 direction = normalize(camF + offR + offU);      // GetPixelDirection, pathtracer.cu:33-40
+            const f3 d0 = normalize(direction);                      // Ray ctor normalises again, CudaRay.cuh:12
+            b.rng0[sid] = make_uint4(rng.x0, rng.x1, rng.x2, rng.x3);
+            b.rng1[sid] = make_uint4(rng.x4, rng.d, ((uint32_t)prm.spp_per_pass << 16), F_PATH);
+            b.weight[sid] = make_float4(1.f, 1.f, 1.f, 0.f);
+            b.rad[sid] = make_float4(0.f, 0.f, 0.f, 1.f);
+            b.pix[sid] = make_float4(0.f, 0.f, 0.f, 0.f);
+            b.dir0[sid] = make_float4(d0.x, d0.y, d0.z, 0.f);
+            b.ray_o[0][sid] = make_float4(cam.pos[0], cam.pos[1], cam.pos[2], 999999.f);
+            b.ray_d[0][sid] = make_float4(d0.x, d0.y, d0.z, 0.f);
+        } else {
+            b.staging[3 * (size_t)sid + 0] = 0.f; b.staging[3 * (size_t)sid + 1] = 0.f; b.staging[3 * (size_t)sid + 2] = 0.f;
+        }
+    }
+    wave_append(live, sid, &b.cnt[0].nActive, b.active[0]);
+    wave_append(live, sid, &b.cnt[0].nPath, b.rq[0]);
+}
+
+// ---------------------------------------------------------------------------------------
+// wf_trace: persistent closest-hit kernel with lane refill.
+// SHADOW: the ray only decides whether the closest hit is the sampled light point
+// (GetLightColor, CudaUtil.cuh:150-166: visible iff |hit.p - P| < EPS, with t_max = |P-p|+1).
+// Any hit at t < (t_max - 1) - 5e-4 proves the closest hit is at least ~4e-4 in front of P,
+// hence not within EPS = 1e-4 of it, so traversal may stop there; what is reported is then
+// some occluder, for which wf_shade's |hit.p - P| < EPS test fails exactly as it would for the
+// closest one.
+// ---------------------------------------------------------------------------------------
+template <bool SHADOW>
+__global__ __launch_bounds__(256)
+void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride)
+{
+    __shared__ int lds_stack[4][kWfLdsStack * 64];
+    const uint32_t* __restrict__ rq = b.rq[SHADOW ? 1 : 0];
+    const float4* __restrict__ ray_o = b.ray_o[SHADOW ? 1 : 0];
+    const float4* __restrict__ ray_d = b.ray_d[SHADOW ? 1 : 0];
+    float2* __restrict__ hitOut = b.hit[SHADOW ? 1 : 0];
+    const uint32_t n = SHADOW ? b.cnt[slot].nShadow : b.cnt[slot].nPath;
+    uint32_t* head = SHADOW ? &b.cnt[slot].headShadow : &b.cnt[slot].headPath;
+    if ((uint32_t)blockIdx.x * 256u >= n) return;      // surplus blocks leave before touching the queue
+
+    const int lane = threadIdx.x & 63;
+    int* stack = &lds_stack[threadIdx.x >> 6][lane];
+    int* ovf = b.ovf + (blockIdx.x * 256 + threadIdx.x);
+
+    uint32_t chunkPos = 0, chunkEnd = 0;   // wave-uniform
+    bool exhausted = false;                // wave-uniform
+    bool hasRay = false;
+    // per-ray registers
+    uint32_t sid = 0;
+    f3 org(0.f, 0.f, 0.f), dir(0.f, 0.f, 1.f), invD(0.f, 0.f, 0.f);
+    float bestT = 0.f, cullB = 0.f, kcull = 0.f, stopBelow = 0.f;
+    int bestPrim = -1, cur = kDone, sp = 0;
+    bool degenerate = false;
+
+    for (;;) {
+        // ---- hand new rays to idle lanes (ballot + mbcnt compaction) ----
+        const unsigned long long idle = __ballot(!hasRay);
+        const int nIdle = __builtin_popcountll(idle);
+        if (!exhausted && (nIdle >= kWfRefill)) {
+            if (chunkPos == chunkEnd) {
+                uint32_t start = 0;
+                if (lane == 0) start = atomicAdd(head, (uint32_t)kWfChunk);
+                start = __builtin_amdgcn_readfirstlane(start);
+                if (start >= n) { exhausted = true; }
+                else { chunkPos = start; chunkEnd = (start + kWfChunk < n) ? start + kWfChunk : n; }
+            }
+            if (!exhausted) {
+                const uint32_t avail = chunkEnd - chunkPos;
+                const uint32_t take = ((uint32_t)nIdle < avail) ? (uint32_t)nIdle : avail;
+                if (!hasRay) {
+                    const uint32_t r = (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+                    if (r < take) {
+                        sid = rq[chunkPos + r];
+                        const float4 o = ray_o[sid], d = ray_d[sid];
+                        org = f3(o.x, o.y, o.z); dir = f3(d.x, d.y, d.z);
+                        const f3 inv(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);                 // inv(), CudaUtil.cuh:60-63
+                        const float L = __builtin_sqrtf(inv.x * inv.x + inv.y * inv.y + inv.z * inv.z);
+                        invD = inv / L;                                                      // Normalize(inv(dir)), :70
+                        degenerate = !(L < __builtin_inff());
+                        kcull = degenerate ? 1.0078125f : 1.0078125f / L;
+                        bestT = o.w; bestPrim = -1; cullB = bestT * kcull;
+                        stopBelow = (o.w - 1.0f) - 5e-4f;
+                        cur = 0; sp = 0;
+                        hasRay = true;
+                    }
+                }
+                chunkPos += take;
+            }
+        }
+        if (__ballot(hasRay) == 0ull) { if (exhausted) break; else continue; }
+
+        if (hasRay) {
+            // ---- while 1: interior nodes until this lane holds a leaf (or is done) ----
+            while (cur >= 0) {
+                const float4 q0 = sc.nodes[4 * cur + 0];
+                const float4 q1 = sc.nodes[4 * cur + 1];
+                const float4 q2 = sc.nodes[4 * cur + 2];
+                const float4 q3 = sc.nodes[4 * cur + 3];
+                float tnL, tnR;
+                bool okL, okR;
+                if (!degenerate) {
+                    okL = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, org, invD, cullB, tnL);
+                    okR = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, org, invD, cullB, tnR);
+                } else {
+                    const f3 inv(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);
+                    okL = box_test_robust(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, org, dir, inv, cullB, tnL);
+                    okR = box_test_robust(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, org, dir, inv, cullB, tnR);
+                }
+                const int refL = __float_as_int(q3.x), refR = __float_as_int(q3.y);
+                if (okL & okR) {
+                    const bool lNear = tnL <= tnR;
+                    const int farRef = lNear ? refR : refL;
+                    if (sp < kWfLdsStack) stack[sp * 64] = farRef; else ovf[(sp - kWfLdsStack) * ovfStride] = farRef;
+                    sp++;
+                    cur = lNear ? refL : refR;
+                } else if (okL) {
+                    cur = refL;
+                } else if (okR) {
+                    cur = refR;
+                } else if (sp == 0) {
+                    cur = kDone;
+                } else {
+                    sp--;
+                    cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride];
+                }
+            }
+            // ---- while 2: the leaf this lane holds ----
+            if (cur != kDone) {
+                const int code = ~cur, first = code >> 3, cnt = code & 7;
+                for (int k = 0; k < cnt; k++) tri_test(sc.tri, first + k, org, dir, bestT, bestPrim);
+                cullB = bestT * kcull;
+                if (SHADOW && bestPrim >= 0 && bestT < stopBelow) { cur = kDone; }
+                else if (sp == 0) { cur = kDone; }
+                else { sp--; cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride]; }
+            }
+            if (cur == kDone) {
+                // spheres, in order, against the triangles' closest t (CudaUtil.cuh:137-145)
+                for (int s = 0; s < sc.n_spheres; s++) {
+                    const float4 c = sc.spheres[4 * s];
+                    float root;
+                    if (sphere_root(f3(c.x, c.y, c.z), c.w, org, dir, bestT, root)) { bestT = root; bestPrim = sc.n_tris + s; }
+                }
+                hitOut[sid] = make_float2(bestT, __int_as_float(bestPrim));
+                hasRay = false;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// wf_shade: one thread per live stream — the body of GetColor_iter's loop
+// (include/CudaUtil.cuh:216-380) for one bounce, plus StartRender's sample loop bookkeeping.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, int slotOut, int slotClear, int listIn)
+{
+    const uint32_t nIn = b.cnt[slotIn].nActive;
+    if (blockIdx.x == 0 && threadIdx.x < 8) ((uint32_t*)&b.cnt[slotClear])[threadIdx.x] = 0;
+    if ((uint32_t)blockIdx.x * 256u >= nIn) return;
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    const bool have = idx < nIn;
+    bool emitPath = false, emitShadow = false, alive = false;
+    uint32_t sid = 0;
+    if (have) {
+        sid = b.active[listIn][idx];
+        const uint4 r0 = b.rng0[sid], r1 = b.rng1[sid];
+        Rng rng; rng.x0 = r0.x; rng.x1 = r0.y; rng.x2 = r0.z; rng.x3 = r0.w; rng.x4 = r1.x; rng.d = r1.y;
+        int samplesLeft = (int)(r1.z >> 16), depth = (int)((r1.z >> 8) & 0xff), refractCnt = (int)(r1.z & 0xff);
+        uint32_t flags = r1.w;
+        const float4 wq = b.weight[sid], rq4 = b.rad[sid], pq = b.pix[sid];
+        f3 weight(wq.x, wq.y, wq.z), radiance(rq4.x, rq4.y, rq4.z), pixelColor(pq.x, pq.y, pq.z);
+        float cosA = wq.w, denom = rq4.w;
+        bool bRefracted = (flags & F_REFR) != 0;
+        const f3 camPos(cam.pos[0], cam.pos[1], cam.pos[2]);
+        const int Nl = sc.n_lights;
+
+        // ---- 1. pending NEE term (GetLightColor tail + CudaUtil.cuh:271-272) ----
+        if (flags & F_SHADOW) {
+            const float2 hs = b.hit[1][sid];
+            const int sprim = __float_as_int(hs.y);
+            const float4 so = b.ray_o[1][sid], sd = b.ray_d[1][sid];
+            const float4 lpq = b.lp[sid], wbq = b.wb[sid];
+            f3 Le(0.f, 0.f, 0.f);
+            if (sprim >= 0) {
+                const f3 hp = f3(so.x, so.y, so.z) + hs.x * f3(sd.x, sd.y, sd.z);
+                if (length(hp - f3(lpq.x, lpq.y, lpq.z)) < kEps) Le = prim_emittance(sc, sprim);
+            }
+            if (flags & F_NEEOK) radiance += ((f3(wbq.x, wbq.y, wbq.z) * Le) * cosA) / denom;
+        }
+        // ---- 2. the traced path ray belongs to the next sample: retire the old path first ----
+        bool streamDone = false;
+        auto retire = [&]() {                                        // pathtracer.cu:79
+            pixelColor += radiance;
+            samplesLeft--;
+            weight = f3(1.f, 1.f, 1.f); radiance = f3(0.f, 0.f, 0.f);
+            depth = 0; refractCnt = 0; bRefracted = false;
+        };
+        if (flags & F_NEWPATH) retire();
+
+        uint32_t nflags = 0;
+        if (flags & F_PATH) {
+            const float2 hp2 = b.hit[0][sid];
+            const int prim = __float_as_int(hp2.y);
+            const float4 po = b.ray_o[0][sid], pd = b.ray_d[0][sid];
+            const f3 rorg(po.x, po.y, po.z), rdir(pd.x, pd.y, pd.z);
+            if (prim < 0) {
+                radiance += weight * f3(0.1f, 0.1f, 0.1f);               // CudaUtil.cuh:375-379
+                retire();
+                if (samplesLeft > 0) nflags = F_PATH; else streamDone = true;
+            } else {
+                // ---- shade a PATH hit: the whole bounce except visibility ----
+                Surf s;
+                make_surf(sc, prim, hp2.x, rorg, rdir, s);
+                if (sqlen(s.m.emittance) > kEps) radiance += weight * s.m.emittance;   // :220-224
+                const float ior = ior_of(s.m);                                          // :231
+                const int lobe = lobe_of(s.m);
+                const f3 wo = -rdir;
+                // NEE sample (:235-245, SamplePrimitive :38-48)
+                const int li = (int)(rng.next() % (uint32_t)Nl);
+                const float4 l0 = sc.lights[4 * li], l1 = sc.lights[4 * li + 1], l2 = sc.lights[4 * li + 2], l3 = sc.lights[4 * li + 3];
+                const f3 LV0(l0.x, l0.y, l0.z), LV1(l0.w, l1.x, l1.y), LV2(l1.z, l1.w, l2.x), LN(l2.y, l2.z, l2.w);
+                const float r1u = __builtin_sqrtf(rng.uniform());
+                const float r2u = rng.uniform();
+                const f3 lightP = (1.f - r1u) * LV0 + (r1u * (1.f - r2u)) * LV1 + (r1u * r2u) * LV2;
+                const float pdfLight = (1.f / l3.x) / ((float)Nl);
+                const f3 toL = lightP - s.p;
+                const f3 wl = normalize(toL);
+                const float ca = dot(LN, normalize(s.p - lightP));
+                cosA = (ca < 0.f) ? 0.f : ca;
+                const f3 brdfcos = lobe_eval(lobe, s.m, ior, s.fr, wo, wl);
+                const bool neeOk = !anynan(brdfcos);
+                const f3 wb = weight * brdfcos;
+                denom = sqlen(s.p - lightP) * pdfLight;
+                // BSDF sample (:283-338)
+                const f3 wi = lobe_sample(lobe, s.m, ior, s.fr, wo, rng);
+                const f3 w1 = lobe_eval(lobe, s.m, ior, s.fr, wo, wi);
+                float w2 = lobe_pdf(lobe, s.m, ior, s.fr, wo, wi);
+                w2 = selmax(w2, 1e-2f);
+                const f3 cw = w1 / w2;
+                if (lobe >= LOBE_REFRACTIVE) bRefracted = (dot(s.fr.n, wo) * dot(s.fr.n, wi)) <= 0.f;   // :307 (loop-carried, Q8)
+                bool terminate = false;
+                f3 nOrg(0.f, 0.f, 0.f);
+                if (sqlen(wi) > kEps) weight *= cw; else terminate = true;
+                if (!terminate) {
+                    nOrg = s.p + s.fr.n * (bRefracted ? -kEps : kEps);                  // :349-350
+                    if (bRefracted) {
+                        if (refractCnt++ > prm.max_refract) terminate = true;           // :351-359 (Depth unchanged)
+                    } else {
+                        if (depth >= prm.rr_bounce) {                                   // :361-373
+                            const float u = rng.uniform();
+                            const float q = selmax(selmin(maxcomp(weight), 1.f), prm.rr_floor);
+                            if (u < q) weight *= (1.f / q); else terminate = true;
+                        }
+                        depth++;
+                        if (depth >= prm.max_bounce) terminate = true;
+                    }
+                }
+                // shadow ray: Ray(p, P - p), t_max = |P - p| + 1 (GetLightColor :152-157)
+                b.ray_o[1][sid] = make_float4(s.p.x, s.p.y, s.p.z, length(toL) + 1.0f);
+                b.ray_d[1][sid] = make_float4(wl.x, wl.y, wl.z, 0.f);
+                b.wb[sid] = make_float4(wb.x, wb.y, wb.z, 0.f);
+                b.lp[sid] = make_float4(lightP.x, lightP.y, lightP.z, 0.f);
+                nflags = F_SHADOW | (neeOk ? F_NEEOK : 0u);
+                if (!terminate) {
+                    b.ray_o[0][sid] = make_float4(nOrg.x, nOrg.y, nOrg.z, 999999.f);
+                    b.ray_d[0][sid] = make_float4(wi.x, wi.y, wi.z, 0.f);
+                    nflags |= F_PATH;
+                } else if (samplesLeft > 1) {
+                    nflags |= F_PATH | F_NEWPATH;      // pre-launch the next sample's camera ray beside the shadow ray
+                }
+            }
+        } else {
+            // only a shadow ray was traced: the last path of the stream ended at the previous bounce
+            retire();
+            streamDone = true;
+        }
+        if (((nflags & F_PATH) && !(nflags & F_SHADOW)) || (nflags & F_NEWPATH)) {
+            const float4 d0 = b.dir0[sid];
+            b.ray_o[0][sid] = make_float4(camPos.x, camPos.y, camPos.z, 999999.f);
+            b.ray_d[0][sid] = d0;
+        }
+        if (streamDone) {
+            const f3 mean = pixelColor / (float)prm.spp_per_pass;          // pathtracer.cu:81
+            b.staging[3 * (size_t)sid + 0] = mean.x; b.staging[3 * (size_t)sid + 1] = mean.y; b.staging[3 * (size_t)sid + 2] = mean.z;
+        } else {
+            if (bRefracted) nflags |= F_REFR;
+            b.rng0[sid] = make_uint4(rng.x0, rng.x1, rng.x2, rng.x3);
+            b.rng1[sid] = make_uint4(rng.x4, rng.d, ((uint32_t)samplesLeft << 16) | ((uint32_t)depth << 8) | (uint32_t)refractCnt, nflags);
+            b.weight[sid] = make_float4(weight.x, weight.y, weight.z, cosA);
+            b.rad[sid] = make_float4(radiance.x, radiance.y, radiance.z, denom);
+            b.pix[sid] = make_float4(pixelColor.x, pixelColor.y, pixelColor.z, 0.f);
+            alive = true;
+            emitPath = (nflags & F_PATH) != 0;
+            emitShadow = (nflags & F_SHADOW) != 0;
+        }
+    }
+    wave_append(alive, sid, &b.cnt[slotOut].nActive, b.active[listIn ^ 1]);
+    wave_append(emitPath, sid, &b.cnt[slotOut].nPath, b.rq[0]);
+    wave_append(emitShadow, sid, &b.cnt[slotOut].nShadow, b.rq[1]);
+}
+
+}  // namespace ptd
+
+// ---------------------------------------------------------------------------------------
+// Host driver
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+// bytes of device scratch the pipeline needs for nStreams streams (16-byte aligned carve)
+size_t ptk_wf_work_bytes(size_t nStreams, int traceBlocks)
+{
+    const size_t n16 = (nStreams + 3) & ~(size_t)3;
+    size_t b = 0;
+    b += n16 * 16 * 8;          // 8 state arrays
+    b += n16 * 16 * 4;          // ray_o/ray_d x2
+    b += n16 * 8 * 2;           // hits
+    b += n16 * 4 * 4;           // active x2, rq x2
+    b += 256;                   // counters
+    b += n16 * 12 + 16;         // staging
+    b += (size_t)traceBlocks * 256 * ptd::kWfOvfLevels * 4;
+    return b + 256;
+}
+
+static void carve(void* work, size_t nStreams, int traceBlocks, ptd::WfBuf& b)
+{
+    const size_t n16 = (nStreams + 3) & ~(size_t)3;
+    char* p = (char*)work;
+    auto take = [&](size_t bytes) { char* q = p; p += (bytes + 15) & ~(size_t)15; return q; };
+    b.rng0 = (uint4*)take(n16 * 16); b.rng1 = (uint4*)take(n16 * 16);
+    b.weight = (float4*)take(n16 * 16); b.rad = (float4*)take(n16 * 16); b.pix = (float4*)take(n16 * 16);
+    b.dir0 = (float4*)take(n16 * 16); b.wb = (float4*)take(n16 * 16); b.lp = (float4*)take(n16 * 16);
+    for (int k = 0; k < 2; k++) { b.ray_o[k] = (float4*)take(n16 * 16); b.ray_d[k] = (float4*)take(n16 * 16); }
+    for (int k = 0; k < 2; k++) b.hit[k] = (float2*)take(n16 * 8);
+    for (int k = 0; k < 2; k++) b.active[k] = (uint32_t*)take(n16 * 4);
+    for (int k = 0; k < 2; k++) b.rq[k] = (uint32_t*)take(n16 * 4);
+    b.cnt = (ptd::WfCounters*)take(256);
+    b.staging = (float*)take(n16 * 12 + 16);
+    b.ovf = (int*)take((size_t)traceBlocks * 256 * ptd::kWfOvfLevels * 4);
+}
+
+const float* ptk_wf_staging(void* work, size_t nStreams, int traceBlocks)
+{
+    ptd::WfBuf b; carve(work, nStreams, traceBlocks, b); return b.staging;
+}
+
+// Runs the whole pipeline for one pt_render_tiles call.  `h_cnt` is pinned host memory
+// (>= 32 bytes) used to poll the live-stream count; ev_* are optional event pairs recorded
+// around every wf_trace<PATH> launch group (NULL to skip).  Returns the iteration count in
+// *iters_out.  Blocks the host until the pipeline has drained (it polls the live count).
+hipError_t ptk_wf_render(const ptd::DevScene* sc, const ptd::DevCamera* cam, const ptd::DevParams* prm,
+                         void* work, int traceBlocks, uint32_t* h_cnt, hipStream_t stream,
+                         hipEvent_t ev_begin, hipEvent_t ev_end, int* iters_out)
+{
+    using namespace ptd;
+    const size_t nStreams = (size_t)prm->n_units * 64;
+    WfBuf b; carve(work, nStreams, traceBlocks, b);
+    hipError_t e;
+    if ((e = hipMemsetAsync(b.cnt, 0, 256, stream)) != hipSuccess) return e;
+    const int nb = (int)((nStreams + 255) / 256);
+    if (ev_begin) { if ((e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e; }
+    hipLaunchKernelGGL(wf_init, dim3(nb), dim3(256), 0, stream, *cam, *prm, b, (uint32_t)nStreams);
+    const int ovfStride = traceBlocks * 256;
+    const int tb = traceBlocks < nb ? traceBlocks : nb;
+    // every sample needs at most max_bounce + (max_refract + 2) bounces, +1 iteration to retire
+    const long long hardCap = (long long)prm->spp_per_pass * (prm->max_bounce + prm->max_refract + 3) + 8;
+    int it = 0;
+    int poll = 16;
+    for (;;) {
+        for (int k = 0; k < poll; k++, it++) {
+            const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
+            hipLaunchKernelGGL(wf_trace<false>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride);
+            hipLaunchKernelGGL(wf_trace<true>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride);
+            hipLaunchKernelGGL(wf_shade, dim3(nb), dim3(256), 0, stream, *sc, *cam, *prm, b, sIn, sOut, sClr, it & 1);
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(h_cnt, &b.cnt[it % 3], 32, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+        if (h_cnt[0] == 0) break;
+        if (it > hardCap) return hipErrorLaunchFailure;      // cannot happen for a well-formed scene; never spin forever
+        if (poll < 64) poll *= 2;
+    }
+    if (ev_end) { if ((e = hipEventRecord(ev_end, stream)) != hipSuccess) return e; }
+    if (iters_out) *iters_out = it;
+    return hipSuccess;
+}
+
+}  // extern "C"

@@ -78,6 +78,8 @@ API = [
     ("pt_dbg_math", C.c_int, [C.c_int32, _P, C.c_int32, _P]),
     ("pt_last_counters", C.c_int, [_P, _P]),
     ("pt_enable_counters", C.c_int, [_P, C.c_int32]),
+    ("pt_set_mode", C.c_int, [_P, C.c_int32]),
+    ("pt_last_iterations", C.c_int, [_P]),
 ]
 
 
@@ -249,6 +251,13 @@ class Scene:
         if n < 0:
             _check(n, "pt_render_timings")
         return out[:n].copy()
+
+    def set_mode(self, mode):
+        """1 = wavefront pipeline (default), 0 = one-kernel state machine."""
+        _check(lib().pt_set_mode(self._h, mode), "pt_set_mode")
+
+    def last_iterations(self):
+        return lib().pt_last_iterations(self._h)
 
     def enable_counters(self, on=True):
         _check(lib().pt_enable_counters(self._h, 1 if on else 0), "pt_enable_counters")

@@ -234,3 +234,18 @@ def test_error_paths():
     bad = nodes.copy(); bad["childL"][0] = 99                   # child index out of range is caught on the host
     with pytest.raises(ptamd.PtError):
         ptamd.Scene(bad, tris)
+
+
+def test_wavefront_pipeline_equals_state_machine_kernel():
+    """The two render paths (queue-driven pipeline, one-kernel state machine) are bit-identical,
+    including refraction chains, on a frame that is not tile-aligned."""
+    sc = ptamd.Scene.from_prims(ptamd.gen_scene(1, 20), make_test_spheres())
+    cam = ptamd.make_camera(150, 77)
+    prm = ptamd.default_params(passes=3, spp_per_pass=5, max_bounce=12)
+    sc.set_mode(1)
+    a = sc.render(cam, prm)
+    iters = sc.last_iterations()
+    sc.set_mode(0)
+    b = sc.render(cam, prm)
+    assert np.array_equal(bits(a), bits(b))
+    assert 5 <= iters <= 5 * (12 + 8 + 3) + 8
