@@ -39,7 +39,7 @@ enum : uint32_t {
 };
 
 struct WfCounters {      // one slot per iteration parity (3 rotating slots)
-    uint32_t nActive, nPath, nShadow, headPath, headShadow, pad[3];
+    uint32_t nActive, nPath, nShadow, headPath, headShadow, nSusp, pad[2];
 };
 
 struct WfBuf {
@@ -59,6 +59,8 @@ struct WfBuf {
     WfCounters* cnt;     // [3]
     float* staging;      // per-pass means, [stream][3]
     int* ovf;            // traversal stack overflow (entries >= kWfLdsStack), [level][thread]
+    int* susp[2];        // suspended traversals (ping-pong by iteration): [record][kSuspInts]
+    uint32_t suspCap;    // records per pool
 };
 
 constexpr int kWfLdsStack = 16;      // stack entries per lane kept in LDS (4 KB / wave -> 8 waves/SIMD fit)
@@ -66,6 +68,13 @@ constexpr int kWfOvfLevels = 32;     // further levels spill to global memory (n
 constexpr int kWfChunk = 256;        // ray ids a wave takes from the global queue per atomic
 constexpr int kWfRefill = 16;        // refill lanes once this many are idle
 constexpr int kDone = (int)0x80000000;
+// Time slicing: every launch is followed by a device-wide dependency (the shade kernel needs all
+// hits), so one ray that visits thousands of nodes would hold up the whole iteration (measured:
+// ~800 us per launch).  A ray that has visited kWfBudget nodes is therefore suspended — cur, sp,
+// closest hit and stack go to a record — and its stream simply waits one iteration; the next
+// launch resumes it.  hit.prim <= -2 encodes "pending, record = -2 - prim".
+constexpr int kWfBudget = 96;
+constexpr int kSuspInts = 4 + kWfLdsStack + kWfOvfLevels;
 
 // wave-aggregated append of one id per participating lane
 PT_DEV void wave_append(bool emit, uint32_t id, uint32_t* counter, uint32_t* list)
@@ -119,6 +128,8 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
             b.dir0[sid] = make_float4(d0.x, d0.y, d0.z, 0.f);
             b.ray_o[0][sid] = make_float4(cam.pos[0], cam.pos[1], cam.pos[2], 999999.f);
             b.ray_d[0][sid] = make_float4(d0.x, d0.y, d0.z, 0.f);
+            b.hit[0][sid] = make_float2(0.f, __int_as_float(-1));
+            b.hit[1][sid] = make_float2(0.f, __int_as_float(-1));
         } else {
             b.staging[3 * (size_t)sid + 0] = 0.f; b.staging[3 * (size_t)sid + 1] = 0.f; b.staging[3 * (size_t)sid + 2] = 0.f;
         }
@@ -129,29 +140,30 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
 
 // ---------------------------------------------------------------------------------------
 // wf_trace: persistent closest-hit kernel with lane refill.
-// SHADOW: the ray only decides whether the closest hit is the sampled light point
+// Shadow rays (queue indices >= nPath): the ray only decides whether the closest hit is the sampled light point
 // (GetLightColor, CudaUtil.cuh:150-166: visible iff |hit.p - P| < EPS, with t_max = |P-p|+1).
 // Any hit at t < (t_max - 1) - 5e-4 proves the closest hit is at least ~4e-4 in front of P,
 // hence not within EPS = 1e-4 of it, so traversal may stop there; what is reported is then
 // some occluder, for which wf_shade's |hit.p - P| < EPS test fails exactly as it would for the
 // closest one.
 // ---------------------------------------------------------------------------------------
-template <bool SHADOW>
 __global__ __launch_bounds__(256)
-void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride)
+void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity)
 {
     __shared__ int lds_stack[4][kWfLdsStack * 64];
-    const uint32_t* __restrict__ rq = b.rq[SHADOW ? 1 : 0];
-    const float4* __restrict__ ray_o = b.ray_o[SHADOW ? 1 : 0];
-    const float4* __restrict__ ray_d = b.ray_d[SHADOW ? 1 : 0];
-    float2* __restrict__ hitOut = b.hit[SHADOW ? 1 : 0];
-    const uint32_t n = SHADOW ? b.cnt[slot].nShadow : b.cnt[slot].nPath;
-    uint32_t* head = SHADOW ? &b.cnt[slot].headShadow : &b.cnt[slot].headPath;
+    // one queue index space: [0, nPath) are path rays, [nPath, nPath + nShadow) shadow rays
+    const uint32_t nPath = b.cnt[slot].nPath;
+    const uint32_t n = nPath + b.cnt[slot].nShadow;
+    uint32_t* head = &b.cnt[slot].headPath;
     if ((uint32_t)blockIdx.x * 256u >= n) return;      // surplus blocks leave before touching the queue
 
     const int lane = threadIdx.x & 63;
     int* stack = &lds_stack[threadIdx.x >> 6][lane];
     int* ovf = b.ovf + (blockIdx.x * 256 + threadIdx.x);
+    const int* __restrict__ suspIn = b.susp[parity ^ 1];
+    int* __restrict__ suspOut = b.susp[parity];
+    // rays a wave takes per queue access: ~n / (2 x resident waves), between 16 and kWfChunk
+    const uint32_t kChunk = (n >> 14) < 16u ? 16u : ((n >> 14) > (uint32_t)kWfChunk ? (uint32_t)kWfChunk : (n >> 14));
 
     uint32_t chunkPos = 0, chunkEnd = 0;   // wave-uniform
     bool exhausted = false;                // wave-uniform
@@ -160,8 +172,9 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride)
     uint32_t sid = 0;
     f3 org(0.f, 0.f, 0.f), dir(0.f, 0.f, 1.f), invD(0.f, 0.f, 0.f);
     float bestT = 0.f, cullB = 0.f, kcull = 0.f, stopBelow = 0.f;
-    int bestPrim = -1, cur = kDone, sp = 0;
-    bool degenerate = false;
+    int bestPrim = -1, cur = kDone, sp = 0, steps = 0;
+    bool degenerate = false, shadow = false;
+    float2* hitOut = b.hit[0];
 
     for (;;) {
         // ---- hand new rays to idle lanes (ballot + mbcnt compaction) ----
@@ -170,10 +183,10 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride)
         if (!exhausted && (nIdle >= kWfRefill)) {
             if (chunkPos == chunkEnd) {
                 uint32_t start = 0;
-                if (lane == 0) start = atomicAdd(head, (uint32_t)kWfChunk);
+                if (lane == 0) start = atomicAdd(head, kChunk);
                 start = __builtin_amdgcn_readfirstlane(start);
                 if (start >= n) { exhausted = true; }
-                else { chunkPos = start; chunkEnd = (start + kWfChunk < n) ? start + kWfChunk : n; }
+                else { chunkPos = start; chunkEnd = (start + kChunk < n) ? start + kChunk : n; }
             }
             if (!exhausted) {
                 const uint32_t avail = chunkEnd - chunkPos;
@@ -181,17 +194,33 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride)
                 if (!hasRay) {
                     const uint32_t r = (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
                     if (r < take) {
-                        sid = rq[chunkPos + r];
-                        const float4 o = ray_o[sid], d = ray_d[sid];
+                        const uint32_t q = chunkPos + r;
+                        shadow = q >= nPath;
+                        sid = shadow ? b.rq[1][q - nPath] : b.rq[0][q];
+                        hitOut = shadow ? b.hit[1] : b.hit[0];
+                        const float4 o = (shadow ? b.ray_o[1] : b.ray_o[0])[sid], d = (shadow ? b.ray_d[1] : b.ray_d[0])[sid];
                         org = f3(o.x, o.y, o.z); dir = f3(d.x, d.y, d.z);
                         const f3 inv(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);                 // inv(), CudaUtil.cuh:60-63
                         const float L = __builtin_sqrtf(inv.x * inv.x + inv.y * inv.y + inv.z * inv.z);
                         invD = inv / L;                                                      // Normalize(inv(dir)), :70
                         degenerate = !(L < __builtin_inff());
                         kcull = degenerate ? 1.0078125f : 1.0078125f / L;
-                        bestT = o.w; bestPrim = -1; cullB = bestT * kcull;
-                        stopBelow = (o.w - 1.0f) - 5e-4f;
-                        cur = 0; sp = 0;
+                        stopBelow = shadow ? (o.w - 1.0f) - 5e-4f : -__builtin_inff();
+                        steps = 0;
+                        const float2 prev = hitOut[sid];
+                        const int pp = __float_as_int(prev.y);
+                        if (pp <= -2) {
+                            // resume a suspended traversal
+                            const int* rec = suspIn + (size_t)(-2 - pp) * kSuspInts;
+                            cur = rec[0]; sp = rec[1]; bestT = __int_as_float(rec[2]); bestPrim = rec[3];
+                            for (int k = 0; k < sp; k++) {
+                                const int v = rec[4 + k];
+                                if (k < kWfLdsStack) stack[k * 64] = v; else ovf[(k - kWfLdsStack) * ovfStride] = v;
+                            }
+                        } else {
+                            bestT = o.w; bestPrim = -1; cur = 0; sp = 0;
+                        }
+                        cullB = bestT * kcull;
                         hasRay = true;
                     }
                 }
@@ -202,7 +231,8 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride)
 
         if (hasRay) {
             // ---- while 1: interior nodes until this lane holds a leaf (or is done) ----
-            while (cur >= 0) {
+            while (cur >= 0 && steps < kWfBudget) {
+                steps++;
                 const float4 q0 = sc.nodes[4 * cur + 0];
                 const float4 q1 = sc.nodes[4 * cur + 1];
                 const float4 q2 = sc.nodes[4 * cur + 2];
@@ -235,16 +265,30 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride)
                     cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride];
                 }
             }
+            if (cur >= 0) {
+                // budget spent with interior work left: suspend (or, if the pool is full, carry on)
+                const uint32_t rec = atomicAdd(&b.cnt[slot].nSusp, 1u);
+                if (rec < b.suspCap) {
+                    int* r = suspOut + (size_t)rec * kSuspInts;
+                    r[0] = cur; r[1] = sp; r[2] = __float_as_int(bestT); r[3] = bestPrim;
+                    for (int k = 0; k < sp; k++) r[4 + k] = (k < kWfLdsStack) ? stack[k * 64] : ovf[(k - kWfLdsStack) * ovfStride];
+                    hitOut[sid] = make_float2(bestT, __int_as_float(-2 - (int)rec));
+                    hasRay = false;
+                    cur = kDone;
+                } else {
+                    steps = -(1 << 28);
+                }
+            } else
             // ---- while 2: the leaf this lane holds ----
             if (cur != kDone) {
                 const int code = ~cur, first = code >> 3, cnt = code & 7;
                 for (int k = 0; k < cnt; k++) tri_test(sc.tri, first + k, org, dir, bestT, bestPrim);
                 cullB = bestT * kcull;
-                if (SHADOW && bestPrim >= 0 && bestT < stopBelow) { cur = kDone; }
+                if (bestPrim >= 0 && bestT < stopBelow) { cur = kDone; }
                 else if (sp == 0) { cur = kDone; }
                 else { sp--; cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride]; }
             }
-            if (cur == kDone) {
+            if (hasRay && cur == kDone) {
                 // spheres, in order, against the triangles' closest t (CudaUtil.cuh:137-145)
                 for (int s = 0; s < sc.n_spheres; s++) {
                     const float4 c = sc.spheres[4 * s];
@@ -284,6 +328,12 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
         bool bRefracted = (flags & F_REFR) != 0;
         const f3 camPos(cam.pos[0], cam.pos[1], cam.pos[2]);
         const int Nl = sc.n_lights;
+        // a ray of this stream is still being traversed (time-sliced): wait one iteration
+        const int pendP = (flags & F_PATH) ? __float_as_int(b.hit[0][sid].y) : -1;
+        const int pendS = (flags & F_SHADOW) ? __float_as_int(b.hit[1][sid].y) : -1;
+        if (pendP <= -2 || pendS <= -2) {
+            alive = true; emitPath = pendP <= -2; emitShadow = pendS <= -2;
+        } else {
 
         // ---- 1. pending NEE term (GetLightColor tail + CudaUtil.cuh:271-272) ----
         if (flags & F_SHADOW) {
@@ -404,6 +454,7 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
             emitPath = (nflags & F_PATH) != 0;
             emitShadow = (nflags & F_SHADOW) != 0;
         }
+        }
     }
     wave_append(alive, sid, &b.cnt[slotOut].nActive, b.active[listIn ^ 1]);
     wave_append(emitPath, sid, &b.cnt[slotOut].nPath, b.rq[0]);
@@ -429,6 +480,7 @@ size_t ptk_wf_work_bytes(size_t nStreams, int traceBlocks)
     b += 256;                   // counters
     b += n16 * 12 + 16;         // staging
     b += (size_t)traceBlocks * 256 * ptd::kWfOvfLevels * 4;
+    b += 2 * ((nStreams / 4 + 1024) * ptd::kSuspInts * 4 + 16);
     return b + 256;
 }
 
@@ -447,6 +499,8 @@ static void carve(void* work, size_t nStreams, int traceBlocks, ptd::WfBuf& b)
     b.cnt = (ptd::WfCounters*)take(256);
     b.staging = (float*)take(n16 * 12 + 16);
     b.ovf = (int*)take((size_t)traceBlocks * 256 * ptd::kWfOvfLevels * 4);
+    b.suspCap = (uint32_t)(nStreams / 4 + 1024);
+    for (int k = 0; k < 2; k++) b.susp[k] = (int*)take((size_t)b.suspCap * ptd::kSuspInts * 4);
 }
 
 const float* ptk_wf_staging(void* work, size_t nStreams, int traceBlocks)
@@ -473,14 +527,14 @@ hipError_t ptk_wf_render(const ptd::DevScene* sc, const ptd::DevCamera* cam, con
     const int ovfStride = traceBlocks * 256;
     const int tb = traceBlocks < nb ? traceBlocks : nb;
     // every sample needs at most max_bounce + (max_refract + 2) bounces, +1 iteration to retire
-    const long long hardCap = (long long)prm->spp_per_pass * (prm->max_bounce + prm->max_refract + 3) + 8;
+    // (time-sliced rays add iterations; 64x is far beyond anything a finite tree can need)
+    const long long hardCap = ((long long)prm->spp_per_pass * (prm->max_bounce + prm->max_refract + 3) + 8) * 64;
     int it = 0;
     int poll = 16;
     for (;;) {
         for (int k = 0; k < poll; k++, it++) {
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
-            hipLaunchKernelGGL(wf_trace<false>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride);
-            hipLaunchKernelGGL(wf_trace<true>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride);
+            hipLaunchKernelGGL(wf_trace, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1);
             hipLaunchKernelGGL(wf_shade, dim3(nb), dim3(256), 0, stream, *sc, *cam, *prm, b, sIn, sOut, sClr, it & 1);
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
