@@ -16,6 +16,7 @@
 
 #include "../../include/pt_api.h"
 #include "pt_device.h"
+#include "../host/accel_build.h"
 
 extern "C" {
 hipError_t ptk_render_units(const ptd::DevScene*, const ptd::DevCamera*, const ptd::DevParams*, float*, unsigned int*, void*, int, int, hipStream_t);
@@ -45,7 +46,8 @@ void pt_set_error(const char* fmt, ...);   // pt_host.cpp
 struct PtScene {
     int device = 0;
     ptd::DevScene dev{};
-    void* d_nodes = nullptr; void* d_tri = nullptr; void* d_shade = nullptr; void* d_mats = nullptr;
+    void* d_nodes = nullptr; void* d_tri = nullptr; void* d_tri_ref = nullptr; void* d_leafbox = nullptr;
+    void* d_shade = nullptr; void* d_mats = nullptr;
     void* d_lights = nullptr; void* d_spheres = nullptr;
     unsigned int* d_unit_counter = nullptr;
     void* d_counters = nullptr;
@@ -134,39 +136,29 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
             }
         }
     }
-    if (max_depth > ptd::kStackDepth) {
-        pt_set_error("pt_scene_create: BVH depth %d exceeds the traversal stack (%d)", max_depth, ptd::kStackDepth);
+    // every triangle must belong to exactly one reference leaf (its box decides acceptance)
+    {
+        std::vector<char> covered((size_t)n_tris, 0);
+        for (int i = 0; i < n_nodes; i++) {
+            const PtBVHNode& n = nodes[i];
+            if (widx[(size_t)i] == -1 && depth[(size_t)i] >= 0 && n.primStart != -1 && n.primEnd != -1)
+                for (int k = n.primStart; k <= n.primEnd; k++) covered[(size_t)k]++;
+        }
+        for (int k = 0; k < n_tris; k++)
+            if (covered[(size_t)k] != 1) { pt_set_error("pt_scene_create: triangle %d is in %d reference leaves", k, (int)covered[(size_t)k]); return PT_ERR_INVALID; }
+    }
+    // ---- traversal tree over the triangles (host/accel_build.cpp) ----
+    PtAccel accel;
+    pt_build_accel(nodes, n_nodes, tris, n_tris, accel);
+    if (accel.depth > ptd::kStackDepth) {
+        pt_set_error("pt_scene_create: traversal tree depth %d exceeds the traversal stack (%d)", accel.depth, ptd::kStackDepth);
         return PT_ERR_UNSUPPORTED;
     }
-    for (int i = 0; i < n_nodes; i++) if (widx[(size_t)i] == 0) widx[(size_t)i] = n_wide++;
-
-    // ---- wide nodes ----
-    auto ref_of = [&](int child) -> int32_t {
-        const PtBVHNode& c = nodes[child];
-        if (c.primStart != -1 && c.primEnd != -1) return ~((c.primStart << 3) | (c.primEnd - c.primStart + 1));
-        return widx[(size_t)child];
-    };
-    std::vector<float> wide;
-    auto push_wide = [&](const PtBVHNode& L, int32_t refL, const PtBVHNode& R, int32_t refR) {
-        const float rec[16] = {L.bMin[0], L.bMin[1], L.bMin[2], L.bMax[0], L.bMax[1], L.bMax[2], R.bMin[0], R.bMin[1],
-                               R.bMin[2], R.bMax[0], R.bMax[1], R.bMax[2], as_float(refL), as_float(refR), 0.f, 0.f};
-        wide.insert(wide.end(), rec, rec + 16);
-    };
-    if (n_wide == 0) {
-        // the root is a leaf: one record whose L side is the root itself and whose R side is "no child"
-        push_wide(nodes[0], ref_of(0), nodes[0], ~0);
-        n_wide = 1;
-    } else {
-        wide.reserve((size_t)n_wide * 16);
-        for (int i = 0; i < n_nodes; i++) {
-            if (widx[(size_t)i] < 0) continue;
-            const PtBVHNode& n = nodes[i];
-            push_wide(nodes[n.childL], ref_of(n.childL), nodes[n.childR], ref_of(n.childR));
-        }
-    }
+    max_depth = accel.depth;
+    n_wide = accel.n_wide;
 
     // ---- triangles: test records, shade records, de-duplicated materials, lights ----
-    std::vector<float> tri((size_t)n_tris * 12), shade((size_t)n_tris * 28), mats, lights;
+    std::vector<float> tri((size_t)n_tris * 12), shade((size_t)n_tris * 28), mats, lights;   // tri: reference order (shading)
     std::map<std::string, int> matIndex;
     int n_lights = 0;
     for (int i = 0; i < n_tris; i++) {
@@ -212,8 +204,10 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     sc->n_lights = n_lights;
     sc->max_depth = max_depth;
     int rc;
-    if ((rc = upload(&sc->d_nodes, wide.data(), wide.size() * 4, sc->bytes)) ||
-        (rc = upload(&sc->d_tri, tri.data(), tri.size() * 4, sc->bytes)) ||
+    if ((rc = upload(&sc->d_nodes, accel.wide.data(), accel.wide.size() * 4, sc->bytes)) ||
+        (rc = upload(&sc->d_tri, accel.tri.data(), accel.tri.size() * 4, sc->bytes)) ||
+        (rc = upload(&sc->d_tri_ref, tri.data(), tri.size() * 4, sc->bytes)) ||
+        (rc = upload(&sc->d_leafbox, accel.leafbox.data(), accel.leafbox.size() * 4, sc->bytes)) ||
         (rc = upload(&sc->d_shade, shade.data(), shade.size() * 4, sc->bytes)) ||
         (rc = upload(&sc->d_mats, mats.data(), mats.size() * 4, sc->bytes)) ||
         (rc = upload(&sc->d_lights, lights.data(), lights.size() * 4, sc->bytes)) ||
@@ -231,6 +225,7 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     HIPCHK(hipGetDeviceProperties(&prop, device));
     sc->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     sc->dev.nodes = (const float4*)sc->d_nodes; sc->dev.tri = (const float4*)sc->d_tri;
+    sc->dev.tri_ref = (const float4*)sc->d_tri_ref; sc->dev.leafbox = (const float4*)sc->d_leafbox;
     sc->dev.shade = (const float4*)sc->d_shade; sc->dev.mats = (const float4*)sc->d_mats;
     sc->dev.lights = (const float4*)sc->d_lights; sc->dev.spheres = (const float4*)sc->d_spheres;
     sc->dev.n_nodes = n_wide; sc->dev.n_tris = n_tris; sc->dev.n_lights = n_lights; sc->dev.n_spheres = n_spheres;
@@ -242,7 +237,7 @@ void pt_scene_destroy(PtScene* s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* p[] = {s->d_nodes, s->d_tri, s->d_shade, s->d_mats, s->d_lights, s->d_spheres, s->d_unit_counter, s->d_counters};
+    void* p[] = {s->d_nodes, s->d_tri, s->d_tri_ref, s->d_leafbox, s->d_shade, s->d_mats, s->d_lights, s->d_spheres, s->d_unit_counter, s->d_counters};
     for (void* q : p) if (q) (void)hipFree(q);
     for (int i = 0; i < PtScene::kEvRing; i++) for (int j = 0; j < 2; j++) if (s->ev[i][j]) (void)hipEventDestroy(s->ev[i][j]);
     if (s->h_poll) (void)hipHostFree(s->h_poll);

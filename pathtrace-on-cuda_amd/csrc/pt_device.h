@@ -3,17 +3,19 @@
 //
 // Everything is 16-byte records read with one global_load_dwordx4 per float4:
 //
-//  wide node (64 B, 4 x float4) — one per INTERIOR node of the reference's flattened tree
-//      (CudaBVHNode[], include/CudaPrimitive.cuh:237-247), holding BOTH children's boxes so
+//  wide node (64 B, 4 x float4) — one per interior node of the traversal tree (a binned-SAH
+//      BVH over the triangles built at upload, host/accel_build.cpp; the reference's own tree
+//      only supplies the leaf boxes that decide acceptance), holding BOTH children's boxes so
 //      one dependent fetch decides two box tests:
 //        q0 = Lmin.x Lmin.y Lmin.z Lmax.x
 //        q1 = Lmax.y Lmax.z Rmin.x Rmin.y
 //        q2 = Rmin.z Rmax.x Rmax.y Rmax.z
 //        q3 = refL refR (int bits) | unused | unused
-//      L = the reference's childL (= flat index + 1), R = childR.
 //      ref >= 0 : index of the child's own wide node
 //      ref <  0 : leaf, ~ref = (primStart << 3) | primCount   (primCount 0 = "no child")
-//  tri test record (48 B, 3 x float4):  (V0,0) (E1,0) (E2,0)        — all a box/triangle test reads
+//  tri test record (48 B, 3 x float4):  (V0,prim) (E1,refLeaf) (E2,0) — all a triangle test reads;
+//      prim = index in the reference's order (tie rule, shading), refLeaf = its reference leaf
+//  reference leaf box (32 B): bMin bMax — read only when Triangle::hit accepts (exact acceptance)
 //  tri shade record (112 B, 7 x float4): N0 N1 N2 T0 T1 T2 B0 B1 B2 (27 f) + material index
 //      read once per accepted closest hit
 //  material (48 B, 3 x float4): emittance albedo specular opacity roughness metallic
@@ -31,8 +33,10 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kBlockThreads = 64 * kWavesPerBlock;
 
 struct DevScene {
-    const float4* nodes;
-    const float4* tri;
+    const float4* nodes;      // traversal tree (SAH over triangles), 4 x float4 per record
+    const float4* tri;        // triangle test records in TREE order: (V0,prim) (E1,refLeaf) (E2,0)
+    const float4* tri_ref;    // (V0,0)(E1,0)(E2,0) in the REFERENCE's order (indexed by primitive), for shading
+    const float4* leafbox;    // the reference's leaf boxes: 2 x float4 per reference leaf
     const float4* shade;
     const float4* mats;
     const float4* lights;

@@ -47,7 +47,7 @@ PT_DEV void make_surf(const DevScene& sc, int prim, float t, const f3& org, cons
 {
     s.p = org + t * dir;                                              // Ray::at
     if (prim < sc.n_tris) {
-        const float4 a = sc.tri[3 * prim], b = sc.tri[3 * prim + 1], c = sc.tri[3 * prim + 2];
+        const float4 a = sc.tri_ref[3 * prim], b = sc.tri_ref[3 * prim + 1], c = sc.tri_ref[3 * prim + 2];
         const f3 V0(a.x, a.y, a.z), E1(b.x, b.y, b.z), E2(c.x, c.y, c.z);
         const f3 T = org - V0;
         const f3 P = cross(dir, E2);

@@ -6,16 +6,17 @@
 // include/CudaPrimitive.cuh:104-108), so among equal t the largest primitive index wins and
 // spheres (tested last, in order) beat triangles.
 //
-// How it differs: the reference walks a 40-byte-per-node array
+// How it differs: the reference walks its own 40-byte-per-node tree
 // depth-first in index order with a 128-entry local-memory stack and culls boxes only
-// against an un-scaled closestT.  Here one 64-byte record holds both children's boxes,
-// children are visited near-first, far children go to a per-lane LDS stack, and boxes are
-// additionally culled against the current closest hit (with 2^-7 relative slack so a box is
-// never dropped on float rounding).  The *slab part* of the box test is the reference's own
-// arithmetic (intersectionAABB, CudaUtil.cuh:65-88: inverse direction normalised, far side
-// scaled by 1.00000024f), so the set of leaves whose box passes is the reference's set
-// minus boxes that lie strictly beyond the closest hit.  The final (t, primitive) is
-// therefore the reference's.
+// against an un-scaled closestT.  Here the tree that is walked is a SAH tree over the
+// triangles built at upload (host/accel_build.cpp) with slightly padded boxes; one 64-byte
+// record holds both children's boxes, children are visited near-first, far children go to a
+// per-lane LDS stack, and boxes are also culled against the current closest hit (with 2^-7
+// relative slack).  Acceptance stays the reference's: a triangle counts iff Triangle::hit
+// passes AND the reference's own slab arithmetic (intersectionAABB, CudaUtil.cuh:65-88:
+// inverse direction normalised, far side scaled by 1.00000024f) passes on that triangle's
+// REFERENCE leaf box (ancestors are implied: float rounding is monotonic and a child's
+// interval lies inside its parent's).  The final (t, primitive) is therefore the reference's.
 #pragma once
 #include "pt_device.h"
 #include "pt_math.h"
@@ -75,11 +76,15 @@ PT_DEV bool box_test_robust(float bminx, float bminy, float bminz, float bmaxx, 
 }
 
 // Moeller-Trumbore with the reference's back-face cull and test order,
-// Triangle::hit, include/CudaPrimitive.cuh:89-118.
-PT_DEV void tri_test(const float4* __restrict__ tri, int i, const f3& org, const f3& dir,
+// Triangle::hit, include/CudaPrimitive.cuh:89-118.  `q` indexes the tree-ordered records; the
+// record carries the triangle's index in the reference's order (tie rule: among equal t the
+// largest reference index wins) and its reference leaf.  A triangle only counts if the
+// reference would have reached it, i.e. if its reference leaf box passes the reference's slab
+// test (degenerate rays: the reference accepts every box).
+PT_DEV void tri_test(const DevScene& sc, int q, const f3& org, const f3& dir, const f3& invD, bool degenerate,
                      float& bestT, int& bestPrim)
 {
-    const float4 a = tri[3 * i], b = tri[3 * i + 1], c = tri[3 * i + 2];
+    const float4 a = sc.tri[3 * q], b = sc.tri[3 * q + 1], c = sc.tri[3 * q + 2];
     const f3 V0(a.x, a.y, a.z), E1(b.x, b.y, b.z), E2(c.x, c.y, c.z);
     const f3 T = org - V0;
     const f3 P = cross(dir, E2);
@@ -93,7 +98,15 @@ PT_DEV void tri_test(const float4* __restrict__ tri, int i, const f3& org, const
     if (u < 0.f || u > det) return;
     const float v = dot(Q, dir);
     if (v < 0.f || (v + u) > det) return;
-    if (t < bestT || i > bestPrim) { bestT = t; bestPrim = i; }
+    const int prim = __float_as_int(a.w);
+    if (!(t < bestT || prim > bestPrim)) return;
+    if (!degenerate) {
+        const int leaf = __float_as_int(b.w);
+        const float4 l0 = sc.leafbox[2 * leaf], l1 = sc.leafbox[2 * leaf + 1];
+        float tn;
+        if (!box_test(l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, org, invD, __builtin_inff(), tn)) return;
+    }
+    bestT = t; bestPrim = prim;
 }
 
 // Sphere::hit root selection, include/CudaPrimitive.cuh:255-272.
@@ -152,7 +165,7 @@ PT_DEV int trace_closest(const DevScene& sc, const f3& org, const f3& dir, float
 
         if (okL && refL < 0) {
             const int code = ~refL, first = code >> 3, cnt = code & 7;
-            for (int k = 0; k < cnt; k++) { tri_test(sc.tri, first + k, org, dir, bestT, bestPrim); if (COUNT) st.tris++; }
+            for (int k = 0; k < cnt; k++) { tri_test(sc, first + k, org, dir, invD, degenerate, bestT, bestPrim); if (COUNT) st.tris++; }
             cullB = bestT * kcull;
             okL = false;
         }
@@ -160,7 +173,7 @@ PT_DEV int trace_closest(const DevScene& sc, const f3& org, const f3& dir, float
             // re-check against the possibly tightened bound (result-neutral: skips boxes beyond the hit)
             if (tnR <= cullB) {
                 const int code = ~refR, first = code >> 3, cnt = code & 7;
-                for (int k = 0; k < cnt; k++) { tri_test(sc.tri, first + k, org, dir, bestT, bestPrim); if (COUNT) st.tris++; }
+                for (int k = 0; k < cnt; k++) { tri_test(sc, first + k, org, dir, invD, degenerate, bestT, bestPrim); if (COUNT) st.tris++; }
                 cullB = bestT * kcull;
             }
             okR = false;

@@ -282,7 +282,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity)
             // ---- while 2: the leaf this lane holds ----
             if (cur != kDone) {
                 const int code = ~cur, first = code >> 3, cnt = code & 7;
-                for (int k = 0; k < cnt; k++) tri_test(sc.tri, first + k, org, dir, bestT, bestPrim);
+                for (int k = 0; k < cnt; k++) tri_test(sc, first + k, org, dir, invD, degenerate, bestT, bestPrim);
                 cullB = bestT * kcull;
                 if (bestPrim >= 0 && bestT < stopBelow) { cur = kDone; }
                 else if (sp == 0) { cur = kDone; }

@@ -1,0 +1,15 @@
+// accel_build.h — device acceleration structure built at upload (see accel_build.cpp).
+#pragma once
+#include <vector>
+#include "../../include/pt_api.h"
+
+constexpr int kAccelMaxDepth = 32;       // == ptd::kStackDepth; the builder never exceeds it
+
+struct PtAccel {
+    std::vector<float> wide;             // n_wide x 16 floats (two child boxes + two refs)
+    std::vector<float> tri;              // n_tris x 12 floats, tree order: (V0,prim) (E1,refLeaf) (E2,0)
+    std::vector<float> leafbox;          // n_leaves x 8 floats: the reference's leaf boxes, verbatim
+    int n_wide = 0, n_leaves = 0, depth = 0;
+};
+
+void pt_build_accel(const PtBVHNode* ref_nodes, int n_ref_nodes, const PtTriangle* tris, int n_tris, PtAccel& out);
