@@ -38,9 +38,14 @@ enum : uint32_t {
     F_NEWPATH = 16,  // that path ray is the NEXT sample's camera ray: retire the old path first
 };
 
-struct WfCounters {      // one slot per iteration parity (3 rotating slots)
-    uint32_t nActive, nPath, nShadow, headPath, headShadow, nSusp, pad[2];
+struct WfCounters {      // one slot per iteration parity (3 rotating slots); every hot word on its own 128-B line
+    uint32_t nActive, padA[31];
+    uint32_t nPath, padB[31];
+    uint32_t nShadow, padC[31];
+    uint32_t headPath, padD[15];
+    uint32_t nSusp, padE[15];
 };
+static_assert(sizeof(WfCounters) == 512, "counter slot is 512 bytes");
 
 struct WfBuf {
     uint4* rng0;         // x0 x1 x2 x3
@@ -89,6 +94,32 @@ PT_DEV void wave_append(bool emit, uint32_t id, uint32_t* counter, uint32_t* lis
     if (emit) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = id;
 }
 
+// block-aggregated append to three lists at once: one atomicAdd per list per 256-thread block.
+// (One atomic per wave was the shade kernel's bottleneck: ~100k returning atomics per launch on
+// one cache line serialise at ~88 per microsecond.)  Must be called by all 256 threads.
+PT_DEV void block_append3(bool e0, bool e1, bool e2, uint32_t id, uint32_t* c0, uint32_t* c1, uint32_t* c2,
+                          uint32_t* l0, uint32_t* l1, uint32_t* l2)
+{
+    __shared__ uint32_t s_cnt[3][4];
+    __shared__ uint32_t s_base[3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m0 = __ballot(e0), m1 = __ballot(e1), m2 = __ballot(e2);
+    if (lane == 0) { s_cnt[0][wave] = __builtin_popcountll(m0); s_cnt[1][wave] = __builtin_popcountll(m1); s_cnt[2][wave] = __builtin_popcountll(m2); }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const uint32_t tot = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
+        uint32_t* c = threadIdx.x == 0 ? c0 : (threadIdx.x == 1 ? c1 : c2);
+        s_base[threadIdx.x] = tot ? atomicAdd(c, tot) : 0u;
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t p0 = s_base[0], p1 = s_base[1], p2 = s_base[2];
+    for (int w = 0; w < wave; w++) { p0 += s_cnt[0][w]; p1 += s_cnt[1][w]; p2 += s_cnt[2][w]; }
+    if (e0) l0[p0 + (uint32_t)__builtin_popcountll(m0 & below)] = id;
+    if (e1) l1[p1 + (uint32_t)__builtin_popcountll(m1 & below)] = id;
+    if (e2) l2[p2 + (uint32_t)__builtin_popcountll(m2 & below)] = id;
+}
+
 // ---------------------------------------------------------------------------------------
 // wf_init: StartRender prologue for every stream (pathtracer.cu:70-74)
 // ---------------------------------------------------------------------------------------
@@ -96,7 +127,6 @@ __global__ __launch_bounds__(256)
 void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
 {
     const uint32_t sid = blockIdx.x * 256u + threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x < 16) { ((uint32_t*)&b.cnt[1])[threadIdx.x & 7] = 0; ((uint32_t*)&b.cnt[2])[threadIdx.x & 7] = 0; }
     bool live = false;
     if (sid < nStreams) {
         const uint32_t unit = sid >> 6, lane = sid & 63;
@@ -134,8 +164,7 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
             b.staging[3 * (size_t)sid + 0] = 0.f; b.staging[3 * (size_t)sid + 1] = 0.f; b.staging[3 * (size_t)sid + 2] = 0.f;
         }
     }
-    wave_append(live, sid, &b.cnt[0].nActive, b.active[0]);
-    wave_append(live, sid, &b.cnt[0].nPath, b.rq[0]);
+    block_append3(live, live, false, sid, &b.cnt[0].nActive, &b.cnt[0].nPath, &b.cnt[0].nShadow, b.active[0], b.rq[0], b.rq[1]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -306,11 +335,11 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity)
 // wf_shade: one thread per live stream — the body of GetColor_iter's loop
 // (include/CudaUtil.cuh:216-380) for one bounce, plus StartRender's sample loop bookkeeping.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 4)
 void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, int slotOut, int slotClear, int listIn)
 {
     const uint32_t nIn = b.cnt[slotIn].nActive;
-    if (blockIdx.x == 0 && threadIdx.x < 8) ((uint32_t*)&b.cnt[slotClear])[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 128) ((uint32_t*)&b.cnt[slotClear])[threadIdx.x] = 0;
     if ((uint32_t)blockIdx.x * 256u >= nIn) return;
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     const bool have = idx < nIn;
@@ -322,22 +351,25 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
         Rng rng; rng.x0 = r0.x; rng.x1 = r0.y; rng.x2 = r0.z; rng.x3 = r0.w; rng.x4 = r1.x; rng.d = r1.y;
         int samplesLeft = (int)(r1.z >> 16), depth = (int)((r1.z >> 8) & 0xff), refractCnt = (int)(r1.z & 0xff);
         uint32_t flags = r1.w;
-        const float4 wq = b.weight[sid], rq4 = b.rad[sid], pq = b.pix[sid];
-        f3 weight(wq.x, wq.y, wq.z), radiance(rq4.x, rq4.y, rq4.z), pixelColor(pq.x, pq.y, pq.z);
+        const float4 wq = b.weight[sid], rq4 = b.rad[sid];
+        f3 weight(wq.x, wq.y, wq.z), radiance(rq4.x, rq4.y, rq4.z);
+        f3 pixelColor(0.f, 0.f, 0.f);        // loaded lazily: only a retiring path touches it
+        bool pixLoaded = false;
         float cosA = wq.w, denom = rq4.w;
         bool bRefracted = (flags & F_REFR) != 0;
         const f3 camPos(cam.pos[0], cam.pos[1], cam.pos[2]);
         const int Nl = sc.n_lights;
         // a ray of this stream is still being traversed (time-sliced): wait one iteration
-        const int pendP = (flags & F_PATH) ? __float_as_int(b.hit[0][sid].y) : -1;
-        const int pendS = (flags & F_SHADOW) ? __float_as_int(b.hit[1][sid].y) : -1;
+        const float2 hitP = (flags & F_PATH) ? b.hit[0][sid] : make_float2(0.f, __int_as_float(-1));
+        const float2 hitS = (flags & F_SHADOW) ? b.hit[1][sid] : make_float2(0.f, __int_as_float(-1));
+        const int pendP = __float_as_int(hitP.y), pendS = __float_as_int(hitS.y);
         if (pendP <= -2 || pendS <= -2) {
             alive = true; emitPath = pendP <= -2; emitShadow = pendS <= -2;
         } else {
 
         // ---- 1. pending NEE term (GetLightColor tail + CudaUtil.cuh:271-272) ----
         if (flags & F_SHADOW) {
-            const float2 hs = b.hit[1][sid];
+            const float2 hs = hitS;
             const int sprim = __float_as_int(hs.y);
             const float4 so = b.ray_o[1][sid], sd = b.ray_d[1][sid];
             const float4 lpq = b.lp[sid], wbq = b.wb[sid];
@@ -351,6 +383,7 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
         // ---- 2. the traced path ray belongs to the next sample: retire the old path first ----
         bool streamDone = false;
         auto retire = [&]() {                                        // pathtracer.cu:79
+            if (!pixLoaded) { const float4 pq = b.pix[sid]; pixelColor = f3(pq.x, pq.y, pq.z); pixLoaded = true; }
             pixelColor += radiance;
             samplesLeft--;
             weight = f3(1.f, 1.f, 1.f); radiance = f3(0.f, 0.f, 0.f);
@@ -360,7 +393,7 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
 
         uint32_t nflags = 0;
         if (flags & F_PATH) {
-            const float2 hp2 = b.hit[0][sid];
+            const float2 hp2 = hitP;
             const int prim = __float_as_int(hp2.y);
             const float4 po = b.ray_o[0][sid], pd = b.ray_d[0][sid];
             const f3 rorg(po.x, po.y, po.z), rdir(pd.x, pd.y, pd.z);
@@ -449,16 +482,15 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
             b.rng1[sid] = make_uint4(rng.x4, rng.d, ((uint32_t)samplesLeft << 16) | ((uint32_t)depth << 8) | (uint32_t)refractCnt, nflags);
             b.weight[sid] = make_float4(weight.x, weight.y, weight.z, cosA);
             b.rad[sid] = make_float4(radiance.x, radiance.y, radiance.z, denom);
-            b.pix[sid] = make_float4(pixelColor.x, pixelColor.y, pixelColor.z, 0.f);
+            if (pixLoaded) b.pix[sid] = make_float4(pixelColor.x, pixelColor.y, pixelColor.z, 0.f);
             alive = true;
             emitPath = (nflags & F_PATH) != 0;
             emitShadow = (nflags & F_SHADOW) != 0;
         }
         }
     }
-    wave_append(alive, sid, &b.cnt[slotOut].nActive, b.active[listIn ^ 1]);
-    wave_append(emitPath, sid, &b.cnt[slotOut].nPath, b.rq[0]);
-    wave_append(emitShadow, sid, &b.cnt[slotOut].nShadow, b.rq[1]);
+    block_append3(alive, emitPath, emitShadow, sid, &b.cnt[slotOut].nActive, &b.cnt[slotOut].nPath, &b.cnt[slotOut].nShadow,
+                  b.active[listIn ^ 1], b.rq[0], b.rq[1]);
 }
 
 }  // namespace ptd
@@ -477,7 +509,7 @@ size_t ptk_wf_work_bytes(size_t nStreams, int traceBlocks)
     b += n16 * 16 * 4;          // ray_o/ray_d x2
     b += n16 * 8 * 2;           // hits
     b += n16 * 4 * 4;           // active x2, rq x2
-    b += 256;                   // counters
+    b += 3 * 512;               // counters
     b += n16 * 12 + 16;         // staging
     b += (size_t)traceBlocks * 256 * ptd::kWfOvfLevels * 4;
     b += 2 * ((nStreams / 4 + 1024) * ptd::kSuspInts * 4 + 16);
@@ -496,7 +528,7 @@ static void carve(void* work, size_t nStreams, int traceBlocks, ptd::WfBuf& b)
     for (int k = 0; k < 2; k++) b.hit[k] = (float2*)take(n16 * 8);
     for (int k = 0; k < 2; k++) b.active[k] = (uint32_t*)take(n16 * 4);
     for (int k = 0; k < 2; k++) b.rq[k] = (uint32_t*)take(n16 * 4);
-    b.cnt = (ptd::WfCounters*)take(256);
+    b.cnt = (ptd::WfCounters*)take(3 * 512);
     b.staging = (float*)take(n16 * 12 + 16);
     b.ovf = (int*)take((size_t)traceBlocks * 256 * ptd::kWfOvfLevels * 4);
     b.suspCap = (uint32_t)(nStreams / 4 + 1024);
@@ -520,7 +552,7 @@ hipError_t ptk_wf_render(const ptd::DevScene* sc, const ptd::DevCamera* cam, con
     const size_t nStreams = (size_t)prm->n_units * 64;
     WfBuf b; carve(work, nStreams, traceBlocks, b);
     hipError_t e;
-    if ((e = hipMemsetAsync(b.cnt, 0, 256, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(b.cnt, 0, 3 * 512, stream)) != hipSuccess) return e;
     const int nb = (int)((nStreams + 255) / 256);
     if (ev_begin) { if ((e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e; }
     hipLaunchKernelGGL(wf_init, dim3(nb), dim3(256), 0, stream, *cam, *prm, b, (uint32_t)nStreams);
@@ -538,7 +570,7 @@ hipError_t ptk_wf_render(const ptd::DevScene* sc, const ptd::DevCamera* cam, con
             hipLaunchKernelGGL(wf_shade, dim3(nb), dim3(256), 0, stream, *sc, *cam, *prm, b, sIn, sOut, sClr, it & 1);
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        if ((e = hipMemcpyAsync(h_cnt, &b.cnt[it % 3], 32, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(h_cnt, &b.cnt[it % 3].nActive, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
         if (h_cnt[0] == 0) break;
         if (it > hardCap) return hipErrorLaunchFailure;      // cannot happen for a well-formed scene; never spin forever
