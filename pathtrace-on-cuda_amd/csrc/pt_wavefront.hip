@@ -14,9 +14,9 @@
 //
 // The traversal kernel is persistent: a wave takes ray ids from a global queue in chunks and,
 // whenever >= 16 of its lanes have finished their ray, hands them new ones (ballot + mbcnt
-// compaction), so lanes do not idle for the longest ray of the wave.  Inside it the classic
-// while-while shape is used: all lanes walk interior nodes until each holds a leaf, then all
-// lanes test triangles.  Shadow rays stop at the first hit that is provably in front of the
+// compaction), so lanes do not idle for the longest ray of the wave.  Each trip of its loop
+// advances every lane by one unit — a node step or one triangle test ("if-if") — so no lane
+// waits for another lane's subtree walk.  Shadow rays stop at the first hit that is provably in front of the
 // sampled light point (result-neutral, see wf_trace).
 //
 // Per-stream arithmetic — order of random draws, every float operation — is exactly that of
@@ -70,7 +70,7 @@ struct WfBuf {
 
 constexpr int kWfLdsStack = 16;      // stack entries per lane kept in LDS (4 KB / wave -> 8 waves/SIMD fit)
 constexpr int kWfOvfLevels = 32;     // further levels spill to global memory (never seen on the config scenes)
-constexpr int kWfChunk = 256;        // ray ids a wave takes from the global queue per atomic
+constexpr int kWfChunk = 1024;       // most ray ids a wave takes from the global queue per atomic
 constexpr int kWfRefill = 16;        // refill lanes once this many are idle
 constexpr int kDone = (int)0x80000000;
 // Time slicing: every launch is followed by a device-wide dependency (the shade kernel needs all
@@ -191,8 +191,9 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity)
     int* ovf = b.ovf + (blockIdx.x * 256 + threadIdx.x);
     const int* __restrict__ suspIn = b.susp[parity ^ 1];
     int* __restrict__ suspOut = b.susp[parity];
-    // rays a wave takes per queue access: ~n / (2 x resident waves), between 16 and kWfChunk
-    const uint32_t kChunk = (n >> 14) < 16u ? 16u : ((n >> 14) > (uint32_t)kWfChunk ? (uint32_t)kWfChunk : (n >> 14));
+    // rays a wave takes per queue access: ~n / (4 x resident waves), between 16 and kWfChunk (one word
+    // saturates near 88 returning atomics per microsecond, so large launches take large chunks)
+    const uint32_t kChunk = (n >> 15) < 16u ? 16u : ((n >> 15) > (uint32_t)kWfChunk ? (uint32_t)kWfChunk : (n >> 15));
 
     uint32_t chunkPos = 0, chunkEnd = 0;   // wave-uniform
     bool exhausted = false;                // wave-uniform
@@ -259,8 +260,27 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity)
         if (__ballot(hasRay) == 0ull) { if (exhausted) break; else continue; }
 
         if (hasRay) {
-            // ---- while 1: interior nodes until this lane holds a leaf (or is done) ----
-            while (cur >= 0 && steps < kWfBudget) {
+            // One scheduling unit per trip for every lane ("if-if"): a lane holding an interior
+            // node does one node step, then a lane holding a leaf tests ONE triangle of it.  (The
+            // classic while-while shape made 64 lanes wait for the slowest lane to reach a leaf
+            // every round: measured 24 % VALU lane utilisation.)
+            if (cur >= 0) {
+                if (steps >= kWfBudget) {
+                    // node budget spent: suspend (or, if the pool is full, carry on)
+                    const uint32_t rec = atomicAdd(&b.cnt[slot].nSusp, 1u);
+                    if (rec < b.suspCap) {
+                        int* r = suspOut + (size_t)rec * kSuspInts;
+                        r[0] = cur; r[1] = sp; r[2] = __float_as_int(bestT); r[3] = bestPrim;
+                        for (int k = 0; k < sp; k++) r[4 + k] = (k < kWfLdsStack) ? stack[k * 64] : ovf[(k - kWfLdsStack) * ovfStride];
+                        hitOut[sid] = make_float2(bestT, __int_as_float(-2 - (int)rec));
+                        hasRay = false;
+                        cur = kDone;
+                    } else {
+                        steps = -(1 << 28);
+                    }
+                }
+            }
+            if (cur >= 0) {
                 steps++;
                 const float4 q0 = sc.nodes[4 * cur + 0];
                 const float4 q1 = sc.nodes[4 * cur + 1];
@@ -293,29 +313,20 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity)
                     sp--;
                     cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride];
                 }
-            }
-            if (cur >= 0) {
-                // budget spent with interior work left: suspend (or, if the pool is full, carry on)
-                const uint32_t rec = atomicAdd(&b.cnt[slot].nSusp, 1u);
-                if (rec < b.suspCap) {
-                    int* r = suspOut + (size_t)rec * kSuspInts;
-                    r[0] = cur; r[1] = sp; r[2] = __float_as_int(bestT); r[3] = bestPrim;
-                    for (int k = 0; k < sp; k++) r[4 + k] = (k < kWfLdsStack) ? stack[k * 64] : ovf[(k - kWfLdsStack) * ovfStride];
-                    hitOut[sid] = make_float2(bestT, __int_as_float(-2 - (int)rec));
-                    hasRay = false;
-                    cur = kDone;
-                } else {
-                    steps = -(1 << 28);
-                }
-            } else
-            // ---- while 2: the leaf this lane holds ----
-            if (cur != kDone) {
+            } else if (hasRay && cur != kDone) {
+                // ---- one triangle of the leaf this lane holds ----
                 const int code = ~cur, first = code >> 3, cnt = code & 7;
-                for (int k = 0; k < cnt; k++) tri_test(sc, first + k, org, dir, invD, degenerate, bestT, bestPrim);
-                cullB = bestT * kcull;
-                if (bestPrim >= 0 && bestT < stopBelow) { cur = kDone; }
-                else if (sp == 0) { cur = kDone; }
-                else { sp--; cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride]; }
+                bool pop = true;
+                if (cnt > 0) {
+                    tri_test(sc, first, org, dir, invD, degenerate, bestT, bestPrim);
+                    cullB = bestT * kcull;
+                    if (bestPrim >= 0 && bestT < stopBelow) { cur = kDone; pop = false; }
+                    else if (cnt > 1) { cur = ~(((first + 1) << 3) | (cnt - 1)); pop = false; }
+                }
+                if (pop) {
+                    if (sp == 0) cur = kDone;
+                    else { sp--; cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride]; }
+                }
             }
             if (hasRay && cur == kDone) {
                 // spheres, in order, against the triangles' closest t (CudaUtil.cuh:137-145)
