@@ -260,10 +260,11 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity)
         if (__ballot(hasRay) == 0ull) { if (exhausted) break; else continue; }
 
         if (hasRay) {
-            // One scheduling unit per trip for every lane ("if-if"): a lane holding an interior
-            // node does one node step, then a lane holding a leaf tests ONE triangle of it.  (The
-            // classic while-while shape made 64 lanes wait for the slowest lane to reach a leaf
-            // every round: measured 24 % VALU lane utilisation.)
+            // Each trip the wave votes: if more lanes hold an interior node than a leaf, the node
+            // lanes do one node step, otherwise the leaf lanes test ONE triangle each.  Only one
+            // code path runs per trip and it always serves the majority.  (The classic while-while
+            // shape made 64 lanes wait for the slowest lane to reach a leaf every round — 24 % VALU
+            // lane utilisation; running both paths every trip, "if-if", gave 29 %.)
             if (cur >= 0) {
                 if (steps >= kWfBudget) {
                     // node budget spent: suspend (or, if the pool is full, carry on)
@@ -280,7 +281,11 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity)
                     }
                 }
             }
-            if (cur >= 0) {
+            // wave vote: run ONE of the two code paths this trip — the one more lanes are waiting for
+            const int nNode = __builtin_popcountll(__ballot(cur >= 0));
+            const int nTri = __builtin_popcountll(__ballot(hasRay && cur < 0 && cur != kDone));
+            const bool doNode = nNode >= nTri;
+            if (doNode && cur >= 0) {
                 steps++;
                 const float4 q0 = sc.nodes[4 * cur + 0];
                 const float4 q1 = sc.nodes[4 * cur + 1];
@@ -313,7 +318,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity)
                     sp--;
                     cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride];
                 }
-            } else if (hasRay && cur != kDone) {
+            } else if (!doNode && hasRay && cur < 0 && cur != kDone) {
                 // ---- one triangle of the leaf this lane holds ----
                 const int code = ~cur, first = code >> 3, cnt = code & 7;
                 bool pop = true;
