@@ -43,34 +43,30 @@ LAT_LON = 187
 
 
 def cpu_baseline(nodes, tris, ncores):
-    """Oracle timed on the host: the same 1080p frame and scene, 1 pass x 1 spp, on a window
-    sized for ~10-30 s of CPU work.  Returns (dict, counters)."""
-    import numpy as np
+    """Oracle timed on the host: the same scene and full 1920x1080 frame, one pass, with the spp
+    chosen (after a short calibration) so that the run is ~10-30 s of CPU work.
+    Returns (dict, counters)."""
     import oracle_lib as O
     O.set_libm(1)
     sc = O.Scene(nodes.tobytes(), tris)
-    # calibrate on 8 rows, then size the timed window
     cam = O.make_camera(W, H)
-    y0 = H // 2 - 4
     t0 = time.time()
-    sc.render(cam, O.make_params(W, H, 1, 1, window=(0, y0, W, y0 + 8)), ncores)
-    per_row = (time.time() - t0) / 8
-    rows = int(max(16, min(H, 15.0 / max(per_row, 1e-6))))
-    rows -= rows % 8
-    ya = (H - rows) // 2
+    sc.render(cam, O.make_params(W, H, 1, 1, window=(0, H // 2 - 32, W, H // 2 + 32)), ncores)   # 64 rows, 1 spp
+    per_frame_spp = (time.time() - t0) * H / 64.0
+    spp = int(max(1, min(64, round(15.0 / max(per_frame_spp, 1e-3)))))
     t0 = time.time()
-    _, cnt = sc.render(cam, O.make_params(W, H, 1, 1, window=(0, ya, W, ya + rows)), ncores)
+    _, cnt = sc.render(cam, O.make_params(W, H, 1, spp), ncores)
     dt = time.time() - t0
     n = int(cnt[5])
     return ({"value": n / dt / 1e6, "unit": "Msamples/s", "cores": ncores, "kind": "port",
-             "sample": f"same scene and 1920x1080 camera, rows {ya}..{ya + rows} x 1920 px, 1 pass x 1 spp "
-                       f"({n} paths, {dt:.1f} s, oracle/pt_oracle.cpp with {ncores} threads)"}, cnt)
+             "sample": f"same scene, full 1920x1080 frame, 1 pass x {spp} spp ({n} paths, {dt:.1f} s, "
+                       f"oracle/pt_oracle.cpp on {ncores} threads)"}, cnt)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=SPP_PER_PASS, help="spp per pass (non-default values are for profiling only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -127,6 +123,7 @@ def main():
         del warm
     barrier()
     scene.render_timings(reset=True)
+    scene.enable_trace_timing(16384)         # HIP event pair around every wf_trace launch, on the launch stream
     t0 = time.perf_counter()
     tr.render()
     gathered = gather_tiles(tr.tiles, rank, world)           # the single exchange step
@@ -159,25 +156,39 @@ def main():
             cpu, cnt = cpu_baseline(nodes, tris, ncores)
         # reference-algorithm counters of this exact workload (full 1080p frame), committed by oracle/gen_counters.py
         tc = json.load(open(os.path.join(ROOT, "tests", "golden", "traversal_counters.json")))["config3_standin"]
-        bps = tc["bytes_per_sample_traversal"] + 24.0 / args.spp
-        # the render call covers `steps` passes; per-step kernel time = its HIP-event duration / steps
-        k_ms = (float(np.sum(kern_ms)) / args.steps) if len(kern_ms) else dt * 1e3 / args.steps
-        launch_samples = float(W) * H * args.spp / world
-        achieved = launch_samples * bps / (k_ms * 1e-3) / 1e9
+        # the dominant kernel is the traversal kernel wf_trace: price it with the traversal terms of
+        # SURVEY.md 8(d) (40 B per node fetched + 36 B per triangle test of the REFERENCE algorithm)
+        bps_trav = (40.0 * tc["nodes_fetched"] + 36.0 * tc["tri_tests"]) / tc["paths"]
+        bps_all = tc["bytes_per_sample_traversal"] + 24.0 / args.spp
+        t_sum_ms, t_launches, t_max_ms = scene.trace_timing()
+        call_samples = float(W) * H * args.spp * args.steps / world          # samples this rank's render call covered
+        if t_launches > 0:
+            k_ms = t_sum_ms / t_launches
+            units_per_launch = call_samples / t_launches
+            achieved = units_per_launch * bps_trav / (k_ms * 1e-3) / 1e9
+        else:   # mode 0 (one-kernel state machine): one launch per call
+            k_ms = float(np.sum(kern_ms)); units_per_launch = call_samples; t_launches = int(len(kern_ms))
+            achieved = units_per_launch * bps_all / (k_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
-                if tj.get("spp_per_pass") == args.spp and tj.get("n_gpus", 1) == world:
+                if tj.get("spp_per_pass") == args.spp and tj.get("n_gpus", 1) == world and tj.get("steps") == args.steps:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "kernel": "wf pipeline (wf_trace + wf_shade), HIP events around the whole render call / steps", "kernel_ms_avg": k_ms, "launches_timed": int(len(kern_ms)),
+                           "kernel": "wf_trace", "kernel_ms_avg": k_ms, "kernel_ms_max": t_max_ms, "launches_timed": int(t_launches),
+                           "kernel_ms_sum": t_sum_ms, "samples_per_launch": units_per_launch,
+                           "algorithmic_bytes_per_sample": bps_trav,
+                           "algorithmic_bytes_per_sample_incl_shading_and_accum": bps_all,
                            "bounce_iterations": int(scene.last_iterations()),
-                           "algorithmic_bytes_per_sample": bps}
+                           "pipeline_ms_per_step": (float(np.sum(kern_ms)) / args.steps) if len(kern_ms) else None,
+                           "note": "algorithmic bytes are those of the REFERENCE traversal (brute force on degenerate rays); this kernel's "
+                                   "own fetches are ~8x fewer and mostly cache hits, so frac > 1 means faster than a bandwidth-perfect "
+                                   "execution of the reference's traversal, not a saturated HBM (DESIGN.md section 5)"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         # a cheap sanity guard on the timed output (not a parity test): finite, plausible brightness

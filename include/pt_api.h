@@ -214,6 +214,12 @@ PT_API int  pt_last_counters(PtScene* s, int64_t* out8);
  * Both produce bit-identical frames.  Environment PTAMD_MODE overrides the default.
  * pt_last_iterations: bounce iterations the pipeline needed for the last render. */
 PT_API int  pt_set_mode(PtScene* s, int32_t mode);
+/* Per-launch timing of the traversal kernel (wf_trace, mode 1): pt_enable_trace_timing makes
+ * every following render record a HIP event pair, on the launch stream, around each of its
+ * first max_launches wf_trace launches (0 = off); pt_trace_timing returns their summed and
+ * maximum duration in ms and how many launches were timed in the last render. */
+PT_API int  pt_enable_trace_timing(PtScene* s, int32_t max_launches);
+PT_API int  pt_trace_timing(PtScene* s, double* sum_ms, int32_t* launches, double* max_ms);
 PT_API int  pt_last_iterations(PtScene* s);
 /* Run the counting build of the kernel on the next pt_render_tiles calls (slower; mode 0). */
 PT_API int  pt_enable_counters(PtScene* s, int32_t on);

@@ -29,7 +29,7 @@ hipError_t ptk_dbg_math(const float*, int, float*, hipStream_t);
 size_t ptk_wf_work_bytes(size_t nStreams, int traceBlocks);
 const float* ptk_wf_staging(void* work, size_t nStreams, int traceBlocks);
 hipError_t ptk_wf_render(const ptd::DevScene*, const ptd::DevCamera*, const ptd::DevParams*, void*, int, uint32_t*, hipStream_t,
-                         hipEvent_t, hipEvent_t, int*);
+                         hipEvent_t, hipEvent_t, int*, hipEvent_t*, int, int*);
 }
 
 void pt_set_error(const char* fmt, ...);   // pt_host.cpp
@@ -59,6 +59,9 @@ struct PtScene {
     int mode = 1;            // 1 = wavefront pipeline (default), 0 = one-kernel state machine
     uint32_t* h_poll = nullptr;   // pinned, for the pipeline's live-stream count
     int last_iters = 0;
+    // optional per-launch timing of the traversal kernel (pt_enable_trace_timing)
+    std::vector<hipEvent_t> trace_ev;
+    int trace_ev_used = 0;
     // ring of HIP event pairs, one pair per render_units launch (pt_render_timings)
     static constexpr int kEvRing = 64;
     hipEvent_t ev[kEvRing][2] = {};
@@ -241,6 +244,7 @@ void pt_scene_destroy(PtScene* s)
     for (void* q : p) if (q) (void)hipFree(q);
     for (int i = 0; i < PtScene::kEvRing; i++) for (int j = 0; j < 2; j++) if (s->ev[i][j]) (void)hipEventDestroy(s->ev[i][j]);
     if (s->h_poll) (void)hipHostFree(s->h_poll);
+    for (hipEvent_t e : s->trace_ev) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -318,7 +322,8 @@ int pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm, float*
     if (s->mode == 1 && !s->count_next) {
         // queue-driven pipeline (pt_wavefront.hip); polls the live-stream count, so it returns once the render has drained
         int iters = 0;
-        HIPCHK(ptk_wf_render(&s->dev, &c, &d, d_work, kTraceBlocks, s->h_poll, stream, s->ev[slot][0], s->ev[slot][1], &iters));
+        HIPCHK(ptk_wf_render(&s->dev, &c, &d, d_work, kTraceBlocks, s->h_poll, stream, s->ev[slot][0], s->ev[slot][1], &iters,
+                             s->trace_ev.empty() ? nullptr : s->trace_ev.data(), (int)s->trace_ev.size() / 2, &s->trace_ev_used));
         s->last_iters = iters;
         s->ev_count++;
         HIPCHK(ptk_sum_passes(ptk_wf_staging(d_work, (size_t)d.n_units * 64, kTraceBlocks), d.passes, perPass, d_tiles, stream));
@@ -402,6 +407,32 @@ int pt_last_counters(PtScene* s, int64_t* out8)
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out8, s->d_counters, 64, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+// Record a HIP event pair around each of the first `max_launches` wf_trace launches of every
+// following render (0 turns it off); pt_trace_timing then reports their summed duration.
+PT_API int pt_enable_trace_timing(PtScene* s, int32_t max_launches)
+{
+    if (!s || max_launches < 0 || max_launches > (1 << 20)) { pt_set_error("pt_enable_trace_timing: bad argument"); return PT_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    for (hipEvent_t e : s->trace_ev) (void)hipEventDestroy(e);
+    s->trace_ev.assign((size_t)max_launches * 2, nullptr);
+    for (auto& e : s->trace_ev) HIPCHK(hipEventCreate(&e));
+    s->trace_ev_used = 0;
+    return PT_OK;
+}
+PT_API int pt_trace_timing(PtScene* s, double* sum_ms, int32_t* launches, double* max_ms)
+{
+    if (!s || !sum_ms || !launches) { pt_set_error("pt_trace_timing: NULL"); return PT_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    double sum = 0, mx = 0;
+    for (int i = 0; i < s->trace_ev_used; i++) {
+        float ms = 0.f;
+        HIPCHK(hipEventSynchronize(s->trace_ev[2 * i + 1]));
+        HIPCHK(hipEventElapsedTime(&ms, s->trace_ev[2 * i], s->trace_ev[2 * i + 1]));
+        sum += ms; if (ms > mx) mx = ms;
+    }
+    *sum_ms = sum; *launches = s->trace_ev_used; if (max_ms) *max_ms = mx;
     return PT_OK;
 }
 PT_API int pt_set_mode(PtScene* s, int32_t mode) { if (!s || mode < 0 || mode > 1) { pt_set_error("pt_set_mode: bad argument"); return PT_ERR_INVALID; } s->mode = mode; return PT_OK; }

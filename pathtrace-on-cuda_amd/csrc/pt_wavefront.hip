@@ -562,7 +562,8 @@ const float* ptk_wf_staging(void* work, size_t nStreams, int traceBlocks)
 // *iters_out.  Blocks the host until the pipeline has drained (it polls the live count).
 hipError_t ptk_wf_render(const ptd::DevScene* sc, const ptd::DevCamera* cam, const ptd::DevParams* prm,
                          void* work, int traceBlocks, uint32_t* h_cnt, hipStream_t stream,
-                         hipEvent_t ev_begin, hipEvent_t ev_end, int* iters_out)
+                         hipEvent_t ev_begin, hipEvent_t ev_end, int* iters_out,
+                         hipEvent_t* trace_ev, int trace_ev_pairs, int* trace_ev_used)
 {
     using namespace ptd;
     const size_t nStreams = (size_t)prm->n_units * 64;
@@ -582,7 +583,10 @@ hipError_t ptk_wf_render(const ptd::DevScene* sc, const ptd::DevCamera* cam, con
     for (;;) {
         for (int k = 0; k < poll; k++, it++) {
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
+            const bool timed = trace_ev && it < trace_ev_pairs;
+            if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
             hipLaunchKernelGGL(wf_trace, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1);
+            if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
             hipLaunchKernelGGL(wf_shade, dim3(nb), dim3(256), 0, stream, *sc, *cam, *prm, b, sIn, sOut, sClr, it & 1);
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -594,6 +598,7 @@ hipError_t ptk_wf_render(const ptd::DevScene* sc, const ptd::DevCamera* cam, con
     }
     if (ev_end) { if ((e = hipEventRecord(ev_end, stream)) != hipSuccess) return e; }
     if (iters_out) *iters_out = it;
+    if (trace_ev_used) *trace_ev_used = trace_ev ? (it < trace_ev_pairs ? it : trace_ev_pairs) : 0;
     return hipSuccess;
 }
 

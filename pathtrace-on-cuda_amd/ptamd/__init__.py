@@ -79,6 +79,8 @@ API = [
     ("pt_last_counters", C.c_int, [_P, _P]),
     ("pt_enable_counters", C.c_int, [_P, C.c_int32]),
     ("pt_set_mode", C.c_int, [_P, C.c_int32]),
+    ("pt_enable_trace_timing", C.c_int, [_P, C.c_int32]),
+    ("pt_trace_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     ("pt_last_iterations", C.c_int, [_P]),
 ]
 
@@ -255,6 +257,15 @@ class Scene:
     def set_mode(self, mode):
         """1 = wavefront pipeline (default), 0 = one-kernel state machine."""
         _check(lib().pt_set_mode(self._h, mode), "pt_set_mode")
+
+    def enable_trace_timing(self, max_launches=8192):
+        _check(lib().pt_enable_trace_timing(self._h, max_launches), "pt_enable_trace_timing")
+
+    def trace_timing(self):
+        """(sum_ms, launches, max_ms) of the wf_trace launches of the last render (HIP events)."""
+        s, n, m = C.c_double(), C.c_int32(), C.c_double()
+        _check(lib().pt_trace_timing(self._h, C.byref(s), C.byref(n), C.byref(m)), "pt_trace_timing")
+        return s.value, n.value, m.value
 
     def last_iterations(self):
         return lib().pt_last_iterations(self._h)
