@@ -221,6 +221,10 @@ PT_API int  pt_set_mode(PtScene* s, int32_t mode);
 PT_API int  pt_enable_trace_timing(PtScene* s, int32_t max_launches);
 PT_API int  pt_trace_timing(PtScene* s, double* sum_ms, int32_t* launches, double* max_ms);
 PT_API int  pt_last_iterations(PtScene* s);
+/* Mode 1 hands the last streams of a render to one run-to-completion launch (wf_drain) once at
+ * most `live_streams` are still alive (0 = never, the default: on MI355X the drain launch measured
+ * slower than the latency-bound iterations it replaces).  Result-neutral. */
+PT_API int  pt_set_drain_threshold(PtScene* s, int32_t live_streams);
 /* Run the counting build of the kernel on the next pt_render_tiles calls (slower; mode 0). */
 PT_API int  pt_enable_counters(PtScene* s, int32_t on);
 

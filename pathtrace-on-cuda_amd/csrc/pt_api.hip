@@ -29,7 +29,7 @@ hipError_t ptk_dbg_math(const float*, int, float*, hipStream_t);
 size_t ptk_wf_work_bytes(size_t nStreams, int traceBlocks);
 const float* ptk_wf_staging(void* work, size_t nStreams, int traceBlocks);
 hipError_t ptk_wf_render(const ptd::DevScene*, const ptd::DevCamera*, const ptd::DevParams*, void*, int, uint32_t*, hipStream_t,
-                         hipEvent_t, hipEvent_t, int*, hipEvent_t*, int, int*);
+                         hipEvent_t, hipEvent_t, int*, hipEvent_t*, int, int*, int);
 }
 
 void pt_set_error(const char* fmt, ...);   // pt_host.cpp
@@ -59,6 +59,7 @@ struct PtScene {
     int mode = 1;            // 1 = wavefront pipeline (default), 0 = one-kernel state machine
     uint32_t* h_poll = nullptr;   // pinned, for the pipeline's live-stream count
     int last_iters = 0;
+    int drain_below = 0;         // hand the last streams to wf_drain once this few are live (0 = never; measured slower than the tail it replaces)
     // optional per-launch timing of the traversal kernel (pt_enable_trace_timing)
     std::vector<hipEvent_t> trace_ev;
     int trace_ev_used = 0;
@@ -224,6 +225,7 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     for (int i = 0; i < PtScene::kEvRing; i++) { HIPCHK(hipEventCreate(&sc->ev[i][0])); HIPCHK(hipEventCreate(&sc->ev[i][1])); }
     HIPCHK(hipHostMalloc((void**)&sc->h_poll, 64, hipHostMallocDefault));
     if (const char* m = getenv("PTAMD_MODE")) sc->mode = atoi(m) ? 1 : 0;
+    if (const char* m = getenv("PTAMD_DRAIN")) sc->drain_below = atoi(m);
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     sc->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -323,7 +325,7 @@ int pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm, float*
         // queue-driven pipeline (pt_wavefront.hip); polls the live-stream count, so it returns once the render has drained
         int iters = 0;
         HIPCHK(ptk_wf_render(&s->dev, &c, &d, d_work, kTraceBlocks, s->h_poll, stream, s->ev[slot][0], s->ev[slot][1], &iters,
-                             s->trace_ev.empty() ? nullptr : s->trace_ev.data(), (int)s->trace_ev.size() / 2, &s->trace_ev_used));
+                             s->trace_ev.empty() ? nullptr : s->trace_ev.data(), (int)s->trace_ev.size() / 2, &s->trace_ev_used, s->drain_below));
         s->last_iters = iters;
         s->ev_count++;
         HIPCHK(ptk_sum_passes(ptk_wf_staging(d_work, (size_t)d.n_units * 64, kTraceBlocks), d.passes, perPass, d_tiles, stream));
@@ -437,6 +439,12 @@ PT_API int pt_trace_timing(PtScene* s, double* sum_ms, int32_t* launches, double
 }
 PT_API int pt_set_mode(PtScene* s, int32_t mode) { if (!s || mode < 0 || mode > 1) { pt_set_error("pt_set_mode: bad argument"); return PT_ERR_INVALID; } s->mode = mode; return PT_OK; }
 PT_API int pt_last_iterations(PtScene* s) { return s ? s->last_iters : -1; }
+PT_API int pt_set_drain_threshold(PtScene* s, int32_t live_streams)
+{
+    if (!s || live_streams < 0) { pt_set_error("pt_set_drain_threshold: bad argument"); return PT_ERR_INVALID; }
+    s->drain_below = live_streams;
+    return PT_OK;
+}
 // Ask the next pt_render_tiles on this scene to run the counting build of the kernel.
 PT_API int pt_enable_counters(PtScene* s, int32_t on) { if (!s) return PT_ERR_INVALID; s->count_next = on != 0; return PT_OK; }
 

@@ -22,6 +22,7 @@
 // Per-stream arithmetic — order of random draws, every float operation — is exactly that of
 // render_units / the reference's GetColor_iter, so images are bit-identical across modes.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "pt_device.h"
 #include "pt_math.h"
 #include "pt_bxdf.h"
@@ -78,7 +79,7 @@ constexpr int kDone = (int)0x80000000;
 // ~800 us per launch).  A ray that has visited kWfBudget nodes is therefore suspended — cur, sp,
 // closest hit and stack go to a record — and its stream simply waits one iteration; the next
 // launch resumes it.  hit.prim <= -2 encodes "pending, record = -2 - prim".
-constexpr int kWfBudget = 96;
+constexpr int kWfBudget = 96;         // node steps per launch when the launch is throughput-bound
 constexpr int kSuspInts = 4 + kWfLdsStack + kWfOvfLevels;
 
 // wave-aggregated append of one id per participating lane
@@ -176,8 +177,8 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
 // some occluder, for which wf_shade's |hit.p - P| < EPS test fails exactly as it would for the
 // closest one.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256)
-void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity)
+__global__ __launch_bounds__(256, 8)
+void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, uint32_t latencyBelow)
 {
     __shared__ int lds_stack[4][kWfLdsStack * 64];
     // one queue index space: [0, nPath) are path rays, [nPath, nPath + nShadow) shadow rays
@@ -189,6 +190,10 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity)
     const int lane = threadIdx.x & 63;
     int* stack = &lds_stack[threadIdx.x >> 6][lane];
     int* ovf = b.ovf + (blockIdx.x * 256 + threadIdx.x);
+    const int budget = kWfBudget;
+    // few rays: the launch is bound by the slowest wave's dependent chain, not by issue slots, so let every
+    // lane advance each trip (both code paths run); many rays: vote, one path per trip
+    const bool latencyBound = n < latencyBelow;
     const int* __restrict__ suspIn = b.susp[parity ^ 1];
     int* __restrict__ suspOut = b.susp[parity];
     // rays a wave takes per queue access: ~n / (4 x resident waves), between 16 and kWfChunk (one word
@@ -266,7 +271,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity)
             // shape made 64 lanes wait for the slowest lane to reach a leaf every round — 24 % VALU
             // lane utilisation; running both paths every trip, "if-if", gave 29 %.)
             if (cur >= 0) {
-                if (steps >= kWfBudget) {
+                if (steps >= budget) {
                     // node budget spent: suspend (or, if the pool is full, carry on)
                     const uint32_t rec = atomicAdd(&b.cnt[slot].nSusp, 1u);
                     if (rec < b.suspCap) {
@@ -284,7 +289,8 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity)
             // wave vote: run ONE of the two code paths this trip — the one more lanes are waiting for
             const int nNode = __builtin_popcountll(__ballot(cur >= 0));
             const int nTri = __builtin_popcountll(__ballot(hasRay && cur < 0 && cur != kDone));
-            const bool doNode = nNode >= nTri;
+            const bool doNode = latencyBound || nNode >= nTri;
+            const bool doTri = latencyBound || !doNode;
             if (doNode && cur >= 0) {
                 steps++;
                 const float4 q0 = sc.nodes[4 * cur + 0];
@@ -318,7 +324,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity)
                     sp--;
                     cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride];
                 }
-            } else if (!doNode && hasRay && cur < 0 && cur != kDone) {
+            } else if (doTri && hasRay && cur < 0 && cur != kDone) {
                 // ---- one triangle of the leaf this lane holds ----
                 const int code = ~cur, first = code >> 3, cnt = code & 7;
                 bool pop = true;
@@ -348,8 +354,165 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity)
 }
 
 // ---------------------------------------------------------------------------------------
-// wf_shade: one thread per live stream — the body of GetColor_iter's loop
-// (include/CudaUtil.cuh:216-380) for one bounce, plus StartRender's sample loop bookkeeping.
+// One bounce of one stream — the body of GetColor_iter's loop (include/CudaUtil.cuh:216-380)
+// plus StartRender's sample-loop bookkeeping (srcs/pathtracer.cu:77-81) — on a register-resident
+// stream state.  Shared by wf_shade (state in HBM, one bounce per launch) and wf_drain (state in
+// registers, runs a stream to its end).
+// ---------------------------------------------------------------------------------------
+struct SState {
+    Rng rng;
+    int samplesLeft, depth, refractCnt;
+    uint32_t flags;                 // F_* of the rays that were traced for this bounce
+    f3 weight, radiance;
+    f3 pixelColor; bool pixLoaded;  // loaded lazily: only a retiring path touches it
+    float cosA, denom;              // pending NEE term ...
+    f3 wb, lightP;                  // ... weight*brdfcos, sampled light point
+    f3 pathO, pathD;                // path ray (traced if F_PATH)
+    f3 shO, shD; float shTmax;      // shadow ray (traced if F_SHADOW)
+};
+
+// Returns true when the stream has finished its last sample.  On return st.flags describes the
+// rays to trace next (F_PATH / F_SHADOW / F_NEWPATH) and the ray fields hold them.
+PT_DEV bool shade_step(const DevScene& sc, const DevCamera& cam, const DevParams& prm, SState& st,
+                       float2 hitP, float2 hitS, const float4* __restrict__ pixPtr, const float4* __restrict__ dir0Ptr)
+{
+    const uint32_t flags = st.flags;
+    bool bRefracted = (flags & F_REFR) != 0;
+    const int Nl = sc.n_lights;
+    // ---- 1. pending NEE term (GetLightColor tail + CudaUtil.cuh:271-272) ----
+    if (flags & F_SHADOW) {
+        const int sprim = __float_as_int(hitS.y);
+        f3 Le(0.f, 0.f, 0.f);
+        if (sprim >= 0) {
+            const f3 hp = st.shO + hitS.x * st.shD;
+            if (length(hp - st.lightP) < kEps) Le = prim_emittance(sc, sprim);
+        }
+        if (flags & F_NEEOK) st.radiance += ((st.wb * Le) * st.cosA) / st.denom;
+    }
+    // ---- 2. the traced path ray belongs to the next sample: retire the old path first ----
+    bool streamDone = false;
+    auto retire = [&]() {                                        // pathtracer.cu:79
+        if (!st.pixLoaded) { const float4 pq = *pixPtr; st.pixelColor = f3(pq.x, pq.y, pq.z); st.pixLoaded = true; }
+        st.pixelColor += st.radiance;
+        st.samplesLeft--;
+        st.weight = f3(1.f, 1.f, 1.f); st.radiance = f3(0.f, 0.f, 0.f);
+        st.depth = 0; st.refractCnt = 0; bRefracted = false;
+    };
+    if (flags & F_NEWPATH) retire();
+
+    uint32_t nflags = 0;
+    if (flags & F_PATH) {
+        const int prim = __float_as_int(hitP.y);
+        const f3 rorg = st.pathO, rdir = st.pathD;
+        if (prim < 0) {
+            st.radiance += st.weight * f3(0.1f, 0.1f, 0.1f);               // CudaUtil.cuh:375-379
+            retire();
+            if (st.samplesLeft > 0) nflags = F_PATH; else streamDone = true;
+        } else {
+            // ---- shade a PATH hit: the whole bounce except visibility ----
+            Surf s;
+            make_surf(sc, prim, hitP.x, rorg, rdir, s);
+            if (sqlen(s.m.emittance) > kEps) st.radiance += st.weight * s.m.emittance;   // :220-224
+            const float ior = ior_of(s.m);                                          // :231
+            const int lobe = lobe_of(s.m);
+            const f3 wo = -rdir;
+            // NEE sample (:235-245, SamplePrimitive :38-48)
+            const int li = (int)(st.rng.next() % (uint32_t)Nl);
+            const float4 l0 = sc.lights[4 * li], l1 = sc.lights[4 * li + 1], l2 = sc.lights[4 * li + 2], l3 = sc.lights[4 * li + 3];
+            const f3 LV0(l0.x, l0.y, l0.z), LV1(l0.w, l1.x, l1.y), LV2(l1.z, l1.w, l2.x), LN(l2.y, l2.z, l2.w);
+            const float r1u = __builtin_sqrtf(st.rng.uniform());
+            const float r2u = st.rng.uniform();
+            const f3 lightP = (1.f - r1u) * LV0 + (r1u * (1.f - r2u)) * LV1 + (r1u * r2u) * LV2;
+            const float pdfLight = (1.f / l3.x) / ((float)Nl);
+            const f3 toL = lightP - s.p;
+            const f3 wl = normalize(toL);
+            const float ca = dot(LN, normalize(s.p - lightP));
+            st.cosA = (ca < 0.f) ? 0.f : ca;
+            const f3 brdfcos = lobe_eval(lobe, s.m, ior, s.fr, wo, wl);
+            const bool neeOk = !anynan(brdfcos);
+            st.wb = st.weight * brdfcos;
+            st.lightP = lightP;
+            st.denom = sqlen(s.p - lightP) * pdfLight;
+            // BSDF sample (:283-338)
+            const f3 wi = lobe_sample(lobe, s.m, ior, s.fr, wo, st.rng);
+            const f3 w1 = lobe_eval(lobe, s.m, ior, s.fr, wo, wi);
+            float w2 = lobe_pdf(lobe, s.m, ior, s.fr, wo, wi);
+            w2 = selmax(w2, 1e-2f);
+            const f3 cw = w1 / w2;
+            if (lobe >= LOBE_REFRACTIVE) bRefracted = (dot(s.fr.n, wo) * dot(s.fr.n, wi)) <= 0.f;   // :307 (loop-carried, Q8)
+            bool terminate = false;
+            f3 nOrg(0.f, 0.f, 0.f);
+            if (sqlen(wi) > kEps) st.weight *= cw; else terminate = true;
+            if (!terminate) {
+                nOrg = s.p + s.fr.n * (bRefracted ? -kEps : kEps);                  // :349-350
+                if (bRefracted) {
+                    if (st.refractCnt++ > prm.max_refract) terminate = true;        // :351-359 (Depth unchanged)
+                } else {
+                    if (st.depth >= prm.rr_bounce) {                                // :361-373
+                        const float u = st.rng.uniform();
+                        const float q = selmax(selmin(maxcomp(st.weight), 1.f), prm.rr_floor);
+                        if (u < q) st.weight *= (1.f / q); else terminate = true;
+                    }
+                    st.depth++;
+                    if (st.depth >= prm.max_bounce) terminate = true;
+                }
+            }
+            // shadow ray: Ray(p, P - p), t_max = |P - p| + 1 (GetLightColor :152-157)
+            st.shO = s.p; st.shD = wl; st.shTmax = length(toL) + 1.0f;
+            nflags = F_SHADOW | (neeOk ? F_NEEOK : 0u);
+            if (!terminate) {
+                st.pathO = nOrg; st.pathD = wi;
+                nflags |= F_PATH;
+            } else if (st.samplesLeft > 1) {
+                nflags |= F_PATH | F_NEWPATH;      // pre-launch the next sample's camera ray beside the shadow ray
+            }
+        }
+    } else {
+        // only a shadow ray was traced: the last path of the stream ended at the previous bounce
+        retire();
+        streamDone = true;
+    }
+    if (((nflags & F_PATH) && !(nflags & F_SHADOW)) || (nflags & F_NEWPATH)) {
+        const float4 d0 = *dir0Ptr;
+        st.pathO = f3(cam.pos[0], cam.pos[1], cam.pos[2]);
+        st.pathD = f3(d0.x, d0.y, d0.z);
+    }
+    if (bRefracted) nflags |= F_REFR;
+    st.flags = nflags;
+    return streamDone;
+}
+
+PT_DEV void load_state(const WfBuf& b, uint32_t sid, SState& st)
+{
+    const uint4 r0 = b.rng0[sid], r1 = b.rng1[sid];
+    st.rng.x0 = r0.x; st.rng.x1 = r0.y; st.rng.x2 = r0.z; st.rng.x3 = r0.w; st.rng.x4 = r1.x; st.rng.d = r1.y;
+    st.samplesLeft = (int)(r1.z >> 16); st.depth = (int)((r1.z >> 8) & 0xff); st.refractCnt = (int)(r1.z & 0xff);
+    st.flags = r1.w;
+    const float4 wq = b.weight[sid], rq4 = b.rad[sid];
+    st.weight = f3(wq.x, wq.y, wq.z); st.radiance = f3(rq4.x, rq4.y, rq4.z);
+    st.cosA = wq.w; st.denom = rq4.w;
+    st.pixelColor = f3(0.f, 0.f, 0.f); st.pixLoaded = false;
+    st.wb = f3(0.f, 0.f, 0.f); st.lightP = f3(0.f, 0.f, 0.f);
+    st.pathO = st.pathD = st.shO = st.shD = f3(0.f, 0.f, 0.f); st.shTmax = 0.f;
+    if (st.flags & F_PATH) {
+        const float4 po = b.ray_o[0][sid], pd = b.ray_d[0][sid];
+        st.pathO = f3(po.x, po.y, po.z); st.pathD = f3(pd.x, pd.y, pd.z);
+    }
+    if (st.flags & F_SHADOW) {
+        const float4 so = b.ray_o[1][sid], sd = b.ray_d[1][sid], lpq = b.lp[sid], wbq = b.wb[sid];
+        st.shO = f3(so.x, so.y, so.z); st.shD = f3(sd.x, sd.y, sd.z); st.shTmax = so.w;
+        st.lightP = f3(lpq.x, lpq.y, lpq.z); st.wb = f3(wbq.x, wbq.y, wbq.z);
+    }
+}
+
+PT_DEV void write_mean(const WfBuf& b, const DevParams& prm, uint32_t sid, const SState& st)
+{
+    const f3 mean = st.pixelColor / (float)prm.spp_per_pass;          // pathtracer.cu:81
+    b.staging[3 * (size_t)sid + 0] = mean.x; b.staging[3 * (size_t)sid + 1] = mean.y; b.staging[3 * (size_t)sid + 2] = mean.z;
+}
+
+// ---------------------------------------------------------------------------------------
+// wf_shade: one thread per live stream, one bounce.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 4)
 void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, int slotOut, int slotClear, int listIn)
@@ -363,150 +526,73 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
     uint32_t sid = 0;
     if (have) {
         sid = b.active[listIn][idx];
-        const uint4 r0 = b.rng0[sid], r1 = b.rng1[sid];
-        Rng rng; rng.x0 = r0.x; rng.x1 = r0.y; rng.x2 = r0.z; rng.x3 = r0.w; rng.x4 = r1.x; rng.d = r1.y;
-        int samplesLeft = (int)(r1.z >> 16), depth = (int)((r1.z >> 8) & 0xff), refractCnt = (int)(r1.z & 0xff);
-        uint32_t flags = r1.w;
-        const float4 wq = b.weight[sid], rq4 = b.rad[sid];
-        f3 weight(wq.x, wq.y, wq.z), radiance(rq4.x, rq4.y, rq4.z);
-        f3 pixelColor(0.f, 0.f, 0.f);        // loaded lazily: only a retiring path touches it
-        bool pixLoaded = false;
-        float cosA = wq.w, denom = rq4.w;
-        bool bRefracted = (flags & F_REFR) != 0;
-        const f3 camPos(cam.pos[0], cam.pos[1], cam.pos[2]);
-        const int Nl = sc.n_lights;
+        SState st;
+        load_state(b, sid, st);
         // a ray of this stream is still being traversed (time-sliced): wait one iteration
-        const float2 hitP = (flags & F_PATH) ? b.hit[0][sid] : make_float2(0.f, __int_as_float(-1));
-        const float2 hitS = (flags & F_SHADOW) ? b.hit[1][sid] : make_float2(0.f, __int_as_float(-1));
+        const float2 hitP = (st.flags & F_PATH) ? b.hit[0][sid] : make_float2(0.f, __int_as_float(-1));
+        const float2 hitS = (st.flags & F_SHADOW) ? b.hit[1][sid] : make_float2(0.f, __int_as_float(-1));
         const int pendP = __float_as_int(hitP.y), pendS = __float_as_int(hitS.y);
         if (pendP <= -2 || pendS <= -2) {
             alive = true; emitPath = pendP <= -2; emitShadow = pendS <= -2;
         } else {
-
-        // ---- 1. pending NEE term (GetLightColor tail + CudaUtil.cuh:271-272) ----
-        if (flags & F_SHADOW) {
-            const float2 hs = hitS;
-            const int sprim = __float_as_int(hs.y);
-            const float4 so = b.ray_o[1][sid], sd = b.ray_d[1][sid];
-            const float4 lpq = b.lp[sid], wbq = b.wb[sid];
-            f3 Le(0.f, 0.f, 0.f);
-            if (sprim >= 0) {
-                const f3 hp = f3(so.x, so.y, so.z) + hs.x * f3(sd.x, sd.y, sd.z);
-                if (length(hp - f3(lpq.x, lpq.y, lpq.z)) < kEps) Le = prim_emittance(sc, sprim);
-            }
-            if (flags & F_NEEOK) radiance += ((f3(wbq.x, wbq.y, wbq.z) * Le) * cosA) / denom;
-        }
-        // ---- 2. the traced path ray belongs to the next sample: retire the old path first ----
-        bool streamDone = false;
-        auto retire = [&]() {                                        // pathtracer.cu:79
-            if (!pixLoaded) { const float4 pq = b.pix[sid]; pixelColor = f3(pq.x, pq.y, pq.z); pixLoaded = true; }
-            pixelColor += radiance;
-            samplesLeft--;
-            weight = f3(1.f, 1.f, 1.f); radiance = f3(0.f, 0.f, 0.f);
-            depth = 0; refractCnt = 0; bRefracted = false;
-        };
-        if (flags & F_NEWPATH) retire();
-
-        uint32_t nflags = 0;
-        if (flags & F_PATH) {
-            const float2 hp2 = hitP;
-            const int prim = __float_as_int(hp2.y);
-            const float4 po = b.ray_o[0][sid], pd = b.ray_d[0][sid];
-            const f3 rorg(po.x, po.y, po.z), rdir(pd.x, pd.y, pd.z);
-            if (prim < 0) {
-                radiance += weight * f3(0.1f, 0.1f, 0.1f);               // CudaUtil.cuh:375-379
-                retire();
-                if (samplesLeft > 0) nflags = F_PATH; else streamDone = true;
+            const bool done = shade_step(sc, cam, prm, st, hitP, hitS, &b.pix[sid], &b.dir0[sid]);
+            if (done) {
+                write_mean(b, prm, sid, st);
             } else {
-                // ---- shade a PATH hit: the whole bounce except visibility ----
-                Surf s;
-                make_surf(sc, prim, hp2.x, rorg, rdir, s);
-                if (sqlen(s.m.emittance) > kEps) radiance += weight * s.m.emittance;   // :220-224
-                const float ior = ior_of(s.m);                                          // :231
-                const int lobe = lobe_of(s.m);
-                const f3 wo = -rdir;
-                // NEE sample (:235-245, SamplePrimitive :38-48)
-                const int li = (int)(rng.next() % (uint32_t)Nl);
-                const float4 l0 = sc.lights[4 * li], l1 = sc.lights[4 * li + 1], l2 = sc.lights[4 * li + 2], l3 = sc.lights[4 * li + 3];
-                const f3 LV0(l0.x, l0.y, l0.z), LV1(l0.w, l1.x, l1.y), LV2(l1.z, l1.w, l2.x), LN(l2.y, l2.z, l2.w);
-                const float r1u = __builtin_sqrtf(rng.uniform());
-                const float r2u = rng.uniform();
-                const f3 lightP = (1.f - r1u) * LV0 + (r1u * (1.f - r2u)) * LV1 + (r1u * r2u) * LV2;
-                const float pdfLight = (1.f / l3.x) / ((float)Nl);
-                const f3 toL = lightP - s.p;
-                const f3 wl = normalize(toL);
-                const float ca = dot(LN, normalize(s.p - lightP));
-                cosA = (ca < 0.f) ? 0.f : ca;
-                const f3 brdfcos = lobe_eval(lobe, s.m, ior, s.fr, wo, wl);
-                const bool neeOk = !anynan(brdfcos);
-                const f3 wb = weight * brdfcos;
-                denom = sqlen(s.p - lightP) * pdfLight;
-                // BSDF sample (:283-338)
-                const f3 wi = lobe_sample(lobe, s.m, ior, s.fr, wo, rng);
-                const f3 w1 = lobe_eval(lobe, s.m, ior, s.fr, wo, wi);
-                float w2 = lobe_pdf(lobe, s.m, ior, s.fr, wo, wi);
-                w2 = selmax(w2, 1e-2f);
-                const f3 cw = w1 / w2;
-                if (lobe >= LOBE_REFRACTIVE) bRefracted = (dot(s.fr.n, wo) * dot(s.fr.n, wi)) <= 0.f;   // :307 (loop-carried, Q8)
-                bool terminate = false;
-                f3 nOrg(0.f, 0.f, 0.f);
-                if (sqlen(wi) > kEps) weight *= cw; else terminate = true;
-                if (!terminate) {
-                    nOrg = s.p + s.fr.n * (bRefracted ? -kEps : kEps);                  // :349-350
-                    if (bRefracted) {
-                        if (refractCnt++ > prm.max_refract) terminate = true;           // :351-359 (Depth unchanged)
-                    } else {
-                        if (depth >= prm.rr_bounce) {                                   // :361-373
-                            const float u = rng.uniform();
-                            const float q = selmax(selmin(maxcomp(weight), 1.f), prm.rr_floor);
-                            if (u < q) weight *= (1.f / q); else terminate = true;
-                        }
-                        depth++;
-                        if (depth >= prm.max_bounce) terminate = true;
-                    }
+                const uint32_t nf = st.flags;
+                b.rng0[sid] = make_uint4(st.rng.x0, st.rng.x1, st.rng.x2, st.rng.x3);
+                b.rng1[sid] = make_uint4(st.rng.x4, st.rng.d, ((uint32_t)st.samplesLeft << 16) | ((uint32_t)st.depth << 8) | (uint32_t)st.refractCnt, nf);
+                b.weight[sid] = make_float4(st.weight.x, st.weight.y, st.weight.z, st.cosA);
+                b.rad[sid] = make_float4(st.radiance.x, st.radiance.y, st.radiance.z, st.denom);
+                if (st.pixLoaded) b.pix[sid] = make_float4(st.pixelColor.x, st.pixelColor.y, st.pixelColor.z, 0.f);
+                if (nf & F_SHADOW) {
+                    b.ray_o[1][sid] = make_float4(st.shO.x, st.shO.y, st.shO.z, st.shTmax);
+                    b.ray_d[1][sid] = make_float4(st.shD.x, st.shD.y, st.shD.z, 0.f);
+                    b.wb[sid] = make_float4(st.wb.x, st.wb.y, st.wb.z, 0.f);
+                    b.lp[sid] = make_float4(st.lightP.x, st.lightP.y, st.lightP.z, 0.f);
                 }
-                // shadow ray: Ray(p, P - p), t_max = |P - p| + 1 (GetLightColor :152-157)
-                b.ray_o[1][sid] = make_float4(s.p.x, s.p.y, s.p.z, length(toL) + 1.0f);
-                b.ray_d[1][sid] = make_float4(wl.x, wl.y, wl.z, 0.f);
-                b.wb[sid] = make_float4(wb.x, wb.y, wb.z, 0.f);
-                b.lp[sid] = make_float4(lightP.x, lightP.y, lightP.z, 0.f);
-                nflags = F_SHADOW | (neeOk ? F_NEEOK : 0u);
-                if (!terminate) {
-                    b.ray_o[0][sid] = make_float4(nOrg.x, nOrg.y, nOrg.z, 999999.f);
-                    b.ray_d[0][sid] = make_float4(wi.x, wi.y, wi.z, 0.f);
-                    nflags |= F_PATH;
-                } else if (samplesLeft > 1) {
-                    nflags |= F_PATH | F_NEWPATH;      // pre-launch the next sample's camera ray beside the shadow ray
+                if (nf & F_PATH) {
+                    b.ray_o[0][sid] = make_float4(st.pathO.x, st.pathO.y, st.pathO.z, 999999.f);
+                    b.ray_d[0][sid] = make_float4(st.pathD.x, st.pathD.y, st.pathD.z, 0.f);
                 }
+                alive = true;
+                emitPath = (nf & F_PATH) != 0;
+                emitShadow = (nf & F_SHADOW) != 0;
             }
-        } else {
-            // only a shadow ray was traced: the last path of the stream ended at the previous bounce
-            retire();
-            streamDone = true;
-        }
-        if (((nflags & F_PATH) && !(nflags & F_SHADOW)) || (nflags & F_NEWPATH)) {
-            const float4 d0 = b.dir0[sid];
-            b.ray_o[0][sid] = make_float4(camPos.x, camPos.y, camPos.z, 999999.f);
-            b.ray_d[0][sid] = d0;
-        }
-        if (streamDone) {
-            const f3 mean = pixelColor / (float)prm.spp_per_pass;          // pathtracer.cu:81
-            b.staging[3 * (size_t)sid + 0] = mean.x; b.staging[3 * (size_t)sid + 1] = mean.y; b.staging[3 * (size_t)sid + 2] = mean.z;
-        } else {
-            if (bRefracted) nflags |= F_REFR;
-            b.rng0[sid] = make_uint4(rng.x0, rng.x1, rng.x2, rng.x3);
-            b.rng1[sid] = make_uint4(rng.x4, rng.d, ((uint32_t)samplesLeft << 16) | ((uint32_t)depth << 8) | (uint32_t)refractCnt, nflags);
-            b.weight[sid] = make_float4(weight.x, weight.y, weight.z, cosA);
-            b.rad[sid] = make_float4(radiance.x, radiance.y, radiance.z, denom);
-            if (pixLoaded) b.pix[sid] = make_float4(pixelColor.x, pixelColor.y, pixelColor.z, 0.f);
-            alive = true;
-            emitPath = (nflags & F_PATH) != 0;
-            emitShadow = (nflags & F_SHADOW) != 0;
-        }
         }
     }
     block_append3(alive, emitPath, emitShadow, sid, &b.cnt[slotOut].nActive, &b.cnt[slotOut].nPath, &b.cnt[slotOut].nShadow,
                   b.active[listIn ^ 1], b.rq[0], b.rq[1]);
+}
+
+// ---------------------------------------------------------------------------------------
+// wf_drain: run every remaining stream to its end inside one launch.
+// The pipeline's bounce iterations each carry a device-wide dependency, and the last third of
+// them serve only the few pixels whose every path runs the full depth (a render of 256 spp
+// needs ~1800 iterations while the average stream is done after ~730).  Once few streams are
+// left, per-launch latency — not throughput — sets the pace, so they are handed to this kernel:
+// one lane per stream, state in registers, rays traced in place (trace_closest), same
+// shade_step.  Pending time-sliced traversals are simply redone (they are deterministic).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlockThreads)
+void wf_drain(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, int listIn)
+{
+    __shared__ int lds_stack[kWavesPerBlock][kStackDepth * 64];
+    const uint32_t nIn = b.cnt[slotIn].nActive;
+    const uint32_t idx = blockIdx.x * (uint32_t)kBlockThreads + threadIdx.x;
+    if (idx >= nIn) return;
+    int* stack = &lds_stack[threadIdx.x >> 6][threadIdx.x & 63];
+    const uint32_t sid = b.active[listIn][idx];
+    SState st;
+    load_state(b, sid, st);
+    for (;;) {
+        float2 hitP = make_float2(0.f, __int_as_float(-1)), hitS = make_float2(0.f, __int_as_float(-1));
+        TraceStats ts{0, 0, 0};
+        if (st.flags & F_SHADOW) { float t; const int prim = trace_closest<false>(sc, st.shO, st.shD, st.shTmax, stack, t, ts); hitS = make_float2(t, __int_as_float(prim)); }
+        if (st.flags & F_PATH) { float t; const int prim = trace_closest<false>(sc, st.pathO, st.pathD, 999999.f, stack, t, ts); hitP = make_float2(t, __int_as_float(prim)); }
+        if (shade_step(sc, cam, prm, st, hitP, hitS, &b.pix[sid], &b.dir0[sid])) break;
+    }
+    write_mean(b, prm, sid, st);
 }
 
 }  // namespace ptd
@@ -563,7 +649,7 @@ const float* ptk_wf_staging(void* work, size_t nStreams, int traceBlocks)
 hipError_t ptk_wf_render(const ptd::DevScene* sc, const ptd::DevCamera* cam, const ptd::DevParams* prm,
                          void* work, int traceBlocks, uint32_t* h_cnt, hipStream_t stream,
                          hipEvent_t ev_begin, hipEvent_t ev_end, int* iters_out,
-                         hipEvent_t* trace_ev, int trace_ev_pairs, int* trace_ev_used)
+                         hipEvent_t* trace_ev, int trace_ev_pairs, int* trace_ev_used, int drainBelow)
 {
     using namespace ptd;
     const size_t nStreams = (size_t)prm->n_units * 64;
@@ -578,6 +664,7 @@ hipError_t ptk_wf_render(const ptd::DevScene* sc, const ptd::DevCamera* cam, con
     // every sample needs at most max_bounce + (max_refract + 2) bounces, +1 iteration to retire
     // (time-sliced rays add iterations; 64x is far beyond anything a finite tree can need)
     const long long hardCap = ((long long)prm->spp_per_pass * (prm->max_bounce + prm->max_refract + 3) + 8) * 64;
+    static const uint32_t latencyBelow = getenv("PTAMD_LAT") ? (uint32_t)atoll(getenv("PTAMD_LAT")) : (1u << 19);
     int it = 0;
     int poll = 16;
     for (;;) {
@@ -585,7 +672,7 @@ hipError_t ptk_wf_render(const ptd::DevScene* sc, const ptd::DevCamera* cam, con
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
             const bool timed = trace_ev && it < trace_ev_pairs;
             if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
-            hipLaunchKernelGGL(wf_trace, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1);
+            hipLaunchKernelGGL(wf_trace, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, latencyBelow);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
             hipLaunchKernelGGL(wf_shade, dim3(nb), dim3(256), 0, stream, *sc, *cam, *prm, b, sIn, sOut, sClr, it & 1);
         }
@@ -593,6 +680,13 @@ hipError_t ptk_wf_render(const ptd::DevScene* sc, const ptd::DevCamera* cam, con
         if ((e = hipMemcpyAsync(h_cnt, &b.cnt[it % 3].nActive, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
         if (h_cnt[0] == 0) break;
+        if (h_cnt[0] <= (uint32_t)drainBelow) {
+            // few streams left: finish them in one launch instead of hundreds of latency-bound iterations
+            const int db = (int)((h_cnt[0] + kBlockThreads - 1) / kBlockThreads);
+            hipLaunchKernelGGL(wf_drain, dim3(db), dim3(kBlockThreads), 0, stream, *sc, *cam, *prm, b, it % 3, it & 1);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            break;
+        }
         if (it > hardCap) return hipErrorLaunchFailure;      // cannot happen for a well-formed scene; never spin forever
         if (poll < 64) poll *= 2;
     }

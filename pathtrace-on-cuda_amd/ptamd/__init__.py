@@ -82,6 +82,7 @@ API = [
     ("pt_enable_trace_timing", C.c_int, [_P, C.c_int32]),
     ("pt_trace_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     ("pt_last_iterations", C.c_int, [_P]),
+    ("pt_set_drain_threshold", C.c_int, [_P, C.c_int32]),
 ]
 
 
@@ -266,6 +267,9 @@ class Scene:
         s, n, m = C.c_double(), C.c_int32(), C.c_double()
         _check(lib().pt_trace_timing(self._h, C.byref(s), C.byref(n), C.byref(m)), "pt_trace_timing")
         return s.value, n.value, m.value
+
+    def set_drain_threshold(self, live_streams):
+        _check(lib().pt_set_drain_threshold(self._h, live_streams), "pt_set_drain_threshold")
 
     def last_iterations(self):
         return lib().pt_last_iterations(self._h)

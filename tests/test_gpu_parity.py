@@ -243,11 +243,17 @@ def test_wavefront_pipeline_equals_state_machine_kernel():
     cam = ptamd.make_camera(150, 77)
     prm = ptamd.default_params(passes=3, spp_per_pass=5, max_bounce=12)
     sc.set_mode(1)
+    sc.set_drain_threshold(0)                 # pure pipeline: every bounce is a trace + shade launch pair
     a = sc.render(cam, prm)
     iters = sc.last_iterations()
+    sc.set_drain_threshold(2000)              # pipeline, then the last <= 2000 streams run to completion in wf_drain
+    a2 = sc.render(cam, prm)
+    assert sc.last_iterations() < iters
+    sc.set_drain_threshold(1 << 30)           # everything drained after the first poll
+    a3 = sc.render(cam, prm)
     sc.set_mode(0)
     b = sc.render(cam, prm)
-    assert np.array_equal(bits(a), bits(b))
+    assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(a2), bits(b)) and np.array_equal(bits(a3), bits(b))
     assert 5 <= iters <= 5 * (12 + 8 + 3) + 8
 
 
