@@ -26,10 +26,11 @@ hipError_t ptk_dbg_raycast(const ptd::DevScene*, const float*, int, float*, int*
 hipError_t ptk_dbg_bxdf(int, const float*, int, float*, hipStream_t);
 hipError_t ptk_dbg_rng(unsigned long long, int, uint32_t*, float*, hipStream_t);
 hipError_t ptk_dbg_math(const float*, int, float*, hipStream_t);
-size_t ptk_wf_work_bytes(size_t nStreams, int traceBlocks);
-const float* ptk_wf_staging(void* work, size_t nStreams, int traceBlocks);
-hipError_t ptk_wf_render(const ptd::DevScene*, const ptd::DevCamera*, const ptd::DevParams*, void*, int, uint32_t*, hipStream_t,
-                         hipEvent_t, hipEvent_t, int*, hipEvent_t*, int, int*, int);
+size_t ptk_wf_work_bytes(size_t nUnits, int traceBlocks);
+int ptk_wf_cohorts(size_t nUnits);
+const float* ptk_wf_staging(void* work);
+hipError_t ptk_wf_render(int, const ptd::DevScene*, const ptd::DevCamera*, const ptd::DevParams*, void*, int, uint32_t*, hipStream_t, hipStream_t*,
+                         hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t*, int*, hipEvent_t*, int, int*, int);
 }
 
 void pt_set_error(const char* fmt, ...);   // pt_host.cpp
@@ -62,7 +63,10 @@ struct PtScene {
     int drain_below = 0;         // hand the last streams to wf_drain once this few are live (0 = never; measured slower than the tail it replaces)
     // optional per-launch timing of the traversal kernel (pt_enable_trace_timing)
     std::vector<hipEvent_t> trace_ev;
-    int trace_ev_used = 0;
+    int trace_ev_used[4] = {0, 0, 0, 0};     // per cohort
+    int trace_ev_per = 0;                    // event pairs per cohort in the last render
+    hipStream_t xstreams[3] = {nullptr, nullptr, nullptr};   // extra streams for concurrent cohorts
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     // ring of HIP event pairs, one pair per render_units launch (pt_render_timings)
     static constexpr int kEvRing = 64;
     hipEvent_t ev[kEvRing][2] = {};
@@ -223,7 +227,9 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     HIPCHK(hipMalloc(&sc->d_counters, 64));
     HIPCHK(hipMemset(sc->d_counters, 0, 64));
     for (int i = 0; i < PtScene::kEvRing; i++) { HIPCHK(hipEventCreate(&sc->ev[i][0])); HIPCHK(hipEventCreate(&sc->ev[i][1])); }
-    HIPCHK(hipHostMalloc((void**)&sc->h_poll, 64, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&sc->h_poll, 4 * 64, hipHostMallocDefault));
+    for (int i = 0; i < 3; i++) { HIPCHK(hipStreamCreateWithFlags(&sc->xstreams[i], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&sc->ev_join[i], hipEventDisableTiming)); }
+    HIPCHK(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
     if (const char* m = getenv("PTAMD_MODE")) sc->mode = atoi(m) ? 1 : 0;
     if (const char* m = getenv("PTAMD_DRAIN")) sc->drain_below = atoi(m);
     hipDeviceProp_t prop;
@@ -246,6 +252,8 @@ void pt_scene_destroy(PtScene* s)
     for (void* q : p) if (q) (void)hipFree(q);
     for (int i = 0; i < PtScene::kEvRing; i++) for (int j = 0; j < 2; j++) if (s->ev[i][j]) (void)hipEventDestroy(s->ev[i][j]);
     if (s->h_poll) (void)hipHostFree(s->h_poll);
+    for (int i = 0; i < 3; i++) { if (s->xstreams[i]) (void)hipStreamDestroy(s->xstreams[i]); if (s->ev_join[i]) (void)hipEventDestroy(s->ev_join[i]); }
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     for (hipEvent_t e : s->trace_ev) (void)hipEventDestroy(e);
     delete s;
 }
@@ -280,6 +288,7 @@ static int fill_params(const PtCamera* cam, const PtParams* prm, ptd::DevParams&
     const long long units = (long long)d.n_tiles_local * prm->passes;
     if (units > 0x7fffffffLL) { pt_set_error("too many work units"); return PT_ERR_INVALID; }
     d.n_units = (int)units;
+    d.unit_base = 0;
     return PT_OK;
 }
 
@@ -294,7 +303,7 @@ int64_t pt_work_bytes(const PtCamera* cam, const PtParams* prm)
     ptd::DevParams d;
     if (fill_params(cam, prm, d)) return -1;
     const int64_t mega = (int64_t)d.n_tiles_local * ptd::kTilePixels * 3 * 4 * prm->passes;
-    const int64_t wave = (int64_t)ptk_wf_work_bytes((size_t)d.n_units * 64, kTraceBlocks);
+    const int64_t wave = (int64_t)ptk_wf_work_bytes((size_t)d.n_units, kTraceBlocks);
     return mega > wave ? mega : wave;
 }
 
@@ -324,11 +333,15 @@ int pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm, float*
     if (s->mode == 1 && !s->count_next) {
         // queue-driven pipeline (pt_wavefront.hip); polls the live-stream count, so it returns once the render has drained
         int iters = 0;
-        HIPCHK(ptk_wf_render(&s->dev, &c, &d, d_work, kTraceBlocks, s->h_poll, stream, s->ev[slot][0], s->ev[slot][1], &iters,
-                             s->trace_ev.empty() ? nullptr : s->trace_ev.data(), (int)s->trace_ev.size() / 2, &s->trace_ev_used, s->drain_below));
+        const int C = ptk_wf_cohorts((size_t)d.n_units);
+        s->trace_ev_per = s->trace_ev.empty() ? 0 : (int)(s->trace_ev.size() / 2) / C;
+        for (int k = 0; k < 4; k++) s->trace_ev_used[k] = 0;
+        HIPCHK(ptk_wf_render(s->device, &s->dev, &c, &d, d_work, kTraceBlocks, s->h_poll, stream, s->xstreams,
+                             s->ev[slot][0], s->ev[slot][1], s->ev_fork, s->ev_join, &iters,
+                             s->trace_ev.empty() ? nullptr : s->trace_ev.data(), (int)s->trace_ev.size() / 2, s->trace_ev_used, s->drain_below));
         s->last_iters = iters;
         s->ev_count++;
-        HIPCHK(ptk_sum_passes(ptk_wf_staging(d_work, (size_t)d.n_units * 64, kTraceBlocks), d.passes, perPass, d_tiles, stream));
+        HIPCHK(ptk_sum_passes(ptk_wf_staging(d_work), d.passes, perPass, d_tiles, stream));
         return PT_OK;
     }
     HIPCHK(hipMemsetAsync(s->d_unit_counter, 0, 4, stream));
@@ -420,7 +433,7 @@ PT_API int pt_enable_trace_timing(PtScene* s, int32_t max_launches)
     for (hipEvent_t e : s->trace_ev) (void)hipEventDestroy(e);
     s->trace_ev.assign((size_t)max_launches * 2, nullptr);
     for (auto& e : s->trace_ev) HIPCHK(hipEventCreate(&e));
-    s->trace_ev_used = 0;
+    for (int k = 0; k < 4; k++) s->trace_ev_used[k] = 0;
     return PT_OK;
 }
 PT_API int pt_trace_timing(PtScene* s, double* sum_ms, int32_t* launches, double* max_ms)
@@ -428,13 +441,17 @@ PT_API int pt_trace_timing(PtScene* s, double* sum_ms, int32_t* launches, double
     if (!s || !sum_ms || !launches) { pt_set_error("pt_trace_timing: NULL"); return PT_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     double sum = 0, mx = 0;
-    for (int i = 0; i < s->trace_ev_used; i++) {
-        float ms = 0.f;
-        HIPCHK(hipEventSynchronize(s->trace_ev[2 * i + 1]));
-        HIPCHK(hipEventElapsedTime(&ms, s->trace_ev[2 * i], s->trace_ev[2 * i + 1]));
-        sum += ms; if (ms > mx) mx = ms;
-    }
-    *sum_ms = sum; *launches = s->trace_ev_used; if (max_ms) *max_ms = mx;
+    int total = 0;
+    for (int c = 0; c < 4; c++)
+        for (int i = 0; i < s->trace_ev_used[c]; i++) {
+            const size_t k = ((size_t)c * s->trace_ev_per + i) * 2;
+            float ms = 0.f;
+            HIPCHK(hipEventSynchronize(s->trace_ev[k + 1]));
+            HIPCHK(hipEventElapsedTime(&ms, s->trace_ev[k], s->trace_ev[k + 1]));
+            sum += ms; if (ms > mx) mx = ms;
+            total++;
+        }
+    *sum_ms = sum; *launches = total; if (max_ms) *max_ms = mx;
     return PT_OK;
 }
 PT_API int pt_set_mode(PtScene* s, int32_t mode) { if (!s || mode < 0 || mode > 1) { pt_set_error("pt_set_mode: bad argument"); return PT_ERR_INVALID; } s->mode = mode; return PT_OK; }

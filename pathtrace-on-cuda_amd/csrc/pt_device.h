@@ -56,7 +56,8 @@ struct DevParams {
     int32_t max_refract, first_pass;
     int32_t rank, world;
     int32_t tiles_x, tiles_y, n_tiles_total, n_tiles_local;
-    int32_t n_units;                     // n_tiles_local * passes
+    int32_t n_units;                     // n_tiles_local * passes (of this launch / cohort)
+    int32_t unit_base;                   // first global unit of this cohort (wavefront pipeline)
 };
 
 }  // namespace ptd

@@ -23,6 +23,8 @@
 // render_units / the reference's GetColor_iter, so images are bit-identical across modes.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <thread>
+#include <vector>
 #include "pt_device.h"
 #include "pt_math.h"
 #include "pt_bxdf.h"
@@ -130,7 +132,7 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
     const uint32_t sid = blockIdx.x * 256u + threadIdx.x;
     bool live = false;
     if (sid < nStreams) {
-        const uint32_t unit = sid >> 6, lane = sid & 63;
+        const uint32_t unit = (uint32_t)prm.unit_base + (sid >> 6), lane = sid & 63;
         const int pass_rel = (int)(unit / (uint32_t)prm.n_tiles_local);
         const int lt = (int)(unit % (uint32_t)prm.n_tiles_local);
         const int tile = lt * prm.world + prm.rank;
@@ -190,7 +192,9 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, uint32_
     const int lane = threadIdx.x & 63;
     int* stack = &lds_stack[threadIdx.x >> 6][lane];
     int* ovf = b.ovf + (blockIdx.x * 256 + threadIdx.x);
-    const int budget = kWfBudget;
+    // node steps a ray may take in this launch before it is suspended: large launches hide long rays,
+    // small (latency-bound) launches must not wait for them
+    const int budget = (n >> 15) < (uint32_t)kWfBudget ? kWfBudget : ((n >> 15) > 1024u ? 1024 : (int)(n >> 15));
     // few rays: the launch is bound by the slowest wave's dependent chain, not by issue slots, so let every
     // lane advance each trip (both code paths run); many rays: vote, one path per trip
     const bool latencyBound = n < latencyBelow;
@@ -602,8 +606,8 @@ void wf_drain(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
 // ---------------------------------------------------------------------------------------
 extern "C" {
 
-// bytes of device scratch the pipeline needs for nStreams streams (16-byte aligned carve)
-size_t ptk_wf_work_bytes(size_t nStreams, int traceBlocks)
+// ---- work buffer: [ staging (all streams) | cohort 0 | cohort 1 | ... ] ----------------------
+static size_t cohort_bytes(size_t nStreams, int traceBlocks)
 {
     const size_t n16 = (nStreams + 3) & ~(size_t)3;
     size_t b = 0;
@@ -612,16 +616,37 @@ size_t ptk_wf_work_bytes(size_t nStreams, int traceBlocks)
     b += n16 * 8 * 2;           // hits
     b += n16 * 4 * 4;           // active x2, rq x2
     b += 3 * 512;               // counters
-    b += n16 * 12 + 16;         // staging
     b += (size_t)traceBlocks * 256 * ptd::kWfOvfLevels * 4;
     b += 2 * ((nStreams / 4 + 1024) * ptd::kSuspInts * 4 + 16);
-    return b + 256;
+    return b + 512;
+}
+static size_t staging_bytes(size_t nStreams) { return ((nStreams * 12 + 16) + 255) & ~(size_t)255; }
+
+// Streams are split into cohorts that run the pipeline concurrently on separate HIP streams
+// (pt_wavefront's per-iteration launches each end in a latency-bound tail; another cohort's
+// kernels fill it, and a cohort's bandwidth-bound shade kernel overlaps another's issue-bound
+// trace kernel).  Cohorts are contiguous unit ranges, so each is a whole number of (tile, pass) units.
+int ptk_wf_cohorts(size_t nUnits)
+{
+    static const int forced = getenv("PTAMD_COHORTS") ? atoi(getenv("PTAMD_COHORTS")) : 0;
+    int c = forced > 0 ? forced : (int)(nUnits * 64 / (8u << 20));     // measured: 2 cohorts pay off from ~8M streams, hurt below
+    if (forced <= 0 && c > 2) c = 2;
+    if (c > 4) c = 4;
+    if (c < 1) c = 1;
+    if ((size_t)c > nUnits) c = (int)(nUnits ? nUnits : 1);
+    return c;
 }
 
-static void carve(void* work, size_t nStreams, int traceBlocks, ptd::WfBuf& b)
+size_t ptk_wf_work_bytes(size_t nUnits, int traceBlocks)
+{
+    const int C = ptk_wf_cohorts(nUnits);
+    const size_t per = (nUnits + C - 1) / C;
+    return staging_bytes(nUnits * 64) + (size_t)C * cohort_bytes(per * 64, traceBlocks) + 256;
+}
+
+static void carve(char* p, size_t nStreams, int traceBlocks, ptd::WfBuf& b)
 {
     const size_t n16 = (nStreams + 3) & ~(size_t)3;
-    char* p = (char*)work;
     auto take = [&](size_t bytes) { char* q = p; p += (bytes + 15) & ~(size_t)15; return q; };
     b.rng0 = (uint4*)take(n16 * 16); b.rng1 = (uint4*)take(n16 * 16);
     b.weight = (float4*)take(n16 * 16); b.rad = (float4*)take(n16 * 16); b.pix = (float4*)take(n16 * 16);
@@ -631,40 +656,32 @@ static void carve(void* work, size_t nStreams, int traceBlocks, ptd::WfBuf& b)
     for (int k = 0; k < 2; k++) b.active[k] = (uint32_t*)take(n16 * 4);
     for (int k = 0; k < 2; k++) b.rq[k] = (uint32_t*)take(n16 * 4);
     b.cnt = (ptd::WfCounters*)take(3 * 512);
-    b.staging = (float*)take(n16 * 12 + 16);
     b.ovf = (int*)take((size_t)traceBlocks * 256 * ptd::kWfOvfLevels * 4);
     b.suspCap = (uint32_t)(nStreams / 4 + 1024);
     for (int k = 0; k < 2; k++) b.susp[k] = (int*)take((size_t)b.suspCap * ptd::kSuspInts * 4);
 }
 
-const float* ptk_wf_staging(void* work, size_t nStreams, int traceBlocks)
-{
-    ptd::WfBuf b; carve(work, nStreams, traceBlocks, b); return b.staging;
-}
+const float* ptk_wf_staging(void* work) { return (const float*)work; }
 
-// Runs the whole pipeline for one pt_render_tiles call.  `h_cnt` is pinned host memory
-// (>= 32 bytes) used to poll the live-stream count; ev_* are optional event pairs recorded
-// around every wf_trace<PATH> launch group (NULL to skip).  Returns the iteration count in
-// *iters_out.  Blocks the host until the pipeline has drained (it polls the live count).
-hipError_t ptk_wf_render(const ptd::DevScene* sc, const ptd::DevCamera* cam, const ptd::DevParams* prm,
-                         void* work, int traceBlocks, uint32_t* h_cnt, hipStream_t stream,
-                         hipEvent_t ev_begin, hipEvent_t ev_end, int* iters_out,
-                         hipEvent_t* trace_ev, int trace_ev_pairs, int* trace_ev_used, int drainBelow)
+// One cohort's pipeline on its own stream.  Blocks the calling host thread until the cohort has
+// drained (it polls the live-stream count every 16..64 iterations).
+static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::DevCamera* cam, ptd::DevParams prm,
+                             ptd::WfBuf b, int traceBlocks, uint32_t* h_cnt, hipStream_t stream,
+                             hipEvent_t* trace_ev, int trace_ev_pairs, int* trace_ev_used, int drainBelow, int* iters_out)
 {
     using namespace ptd;
-    const size_t nStreams = (size_t)prm->n_units * 64;
-    WfBuf b; carve(work, nStreams, traceBlocks, b);
     hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return e;
+    const size_t nStreams = (size_t)prm.n_units * 64;
     if ((e = hipMemsetAsync(b.cnt, 0, 3 * 512, stream)) != hipSuccess) return e;
     const int nb = (int)((nStreams + 255) / 256);
-    if (ev_begin) { if ((e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e; }
-    hipLaunchKernelGGL(wf_init, dim3(nb), dim3(256), 0, stream, *cam, *prm, b, (uint32_t)nStreams);
+    hipLaunchKernelGGL(wf_init, dim3(nb), dim3(256), 0, stream, *cam, prm, b, (uint32_t)nStreams);
     const int ovfStride = traceBlocks * 256;
     const int tb = traceBlocks < nb ? traceBlocks : nb;
     // every sample needs at most max_bounce + (max_refract + 2) bounces, +1 iteration to retire
     // (time-sliced rays add iterations; 64x is far beyond anything a finite tree can need)
-    const long long hardCap = ((long long)prm->spp_per_pass * (prm->max_bounce + prm->max_refract + 3) + 8) * 64;
-    static const uint32_t latencyBelow = getenv("PTAMD_LAT") ? (uint32_t)atoll(getenv("PTAMD_LAT")) : (1u << 19);
+    const long long hardCap = ((long long)prm.spp_per_pass * (prm.max_bounce + prm.max_refract + 3) + 8) * 64;
+    static const uint32_t latencyBelow = getenv("PTAMD_LAT") ? (uint32_t)atoll(getenv("PTAMD_LAT")) : 0u;
     int it = 0;
     int poll = 16;
     for (;;) {
@@ -674,7 +691,7 @@ hipError_t ptk_wf_render(const ptd::DevScene* sc, const ptd::DevCamera* cam, con
             if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
             hipLaunchKernelGGL(wf_trace, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, latencyBelow);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
-            hipLaunchKernelGGL(wf_shade, dim3(nb), dim3(256), 0, stream, *sc, *cam, *prm, b, sIn, sOut, sClr, it & 1);
+            hipLaunchKernelGGL(wf_shade, dim3(nb), dim3(256), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(h_cnt, &b.cnt[it % 3].nActive, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
@@ -683,16 +700,67 @@ hipError_t ptk_wf_render(const ptd::DevScene* sc, const ptd::DevCamera* cam, con
         if (h_cnt[0] <= (uint32_t)drainBelow) {
             // few streams left: finish them in one launch instead of hundreds of latency-bound iterations
             const int db = (int)((h_cnt[0] + kBlockThreads - 1) / kBlockThreads);
-            hipLaunchKernelGGL(wf_drain, dim3(db), dim3(kBlockThreads), 0, stream, *sc, *cam, *prm, b, it % 3, it & 1);
+            hipLaunchKernelGGL(wf_drain, dim3(db), dim3(kBlockThreads), 0, stream, *sc, *cam, prm, b, it % 3, it & 1);
             if ((e = hipGetLastError()) != hipSuccess) return e;
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
             break;
         }
         if (it > hardCap) return hipErrorLaunchFailure;      // cannot happen for a well-formed scene; never spin forever
         if (poll < 64) poll *= 2;
     }
-    if (ev_end) { if ((e = hipEventRecord(ev_end, stream)) != hipSuccess) return e; }
     if (iters_out) *iters_out = it;
     if (trace_ev_used) *trace_ev_used = trace_ev ? (it < trace_ev_pairs ? it : trace_ev_pairs) : 0;
+    return hipSuccess;
+}
+
+// Runs the whole pipeline for one pt_render_tiles call.  `stream` is the caller's stream;
+// `xstreams` are up to 3 extra streams owned by the scene; `h_cnt` holds one pinned poll word
+// (64 B apart) per cohort.  ev_begin/ev_end bracket the whole render on `stream`.  trace_ev:
+// optional event pairs, split evenly between cohorts; trace_ev_used[c] = pairs used by cohort c.
+// Blocks the host until the render has drained.
+hipError_t ptk_wf_render(int device, const ptd::DevScene* sc, const ptd::DevCamera* cam, const ptd::DevParams* prm,
+                         void* work, int traceBlocks, uint32_t* h_cnt, hipStream_t stream, hipStream_t* xstreams,
+                         hipEvent_t ev_begin, hipEvent_t ev_end, hipEvent_t ev_fork, hipEvent_t* ev_join, int* iters_out,
+                         hipEvent_t* trace_ev, int trace_ev_pairs, int* trace_ev_used, int drainBelow)
+{
+    using namespace ptd;
+    const size_t nUnits = (size_t)prm->n_units;
+    const int C = ptk_wf_cohorts(nUnits);
+    const size_t per = (nUnits + C - 1) / C;
+    char* base = (char*)work;
+    float* staging = (float*)base;
+    char* p = base + staging_bytes(nUnits * 64);
+    hipError_t e;
+    if (ev_begin) { if ((e = hipEventRecord(ev_begin, stream)) != hipSuccess) return e; }
+    if (C > 1) { if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e; }
+    std::vector<hipError_t> rc((size_t)C, hipSuccess);
+    std::vector<int> iters((size_t)C, 0);
+    std::vector<std::thread> th;
+    const int evPer = trace_ev ? trace_ev_pairs / C : 0;
+    for (int c = 0; c < C; c++) {
+        DevParams cp = *prm;
+        const size_t u0 = (size_t)c * per, u1 = (u0 + per < nUnits) ? u0 + per : nUnits;
+        cp.unit_base = (int)u0; cp.n_units = (int)(u1 > u0 ? u1 - u0 : 0);
+        WfBuf b; carve(p + (size_t)c * cohort_bytes(per * 64, traceBlocks), per * 64, traceBlocks, b);
+        b.staging = staging + u0 * 64 * 3;
+        hipStream_t cs = (c == 0) ? stream : xstreams[c - 1];
+        if (c > 0) { if ((e = hipStreamWaitEvent(cs, ev_fork, 0)) != hipSuccess) return e; }
+        hipEvent_t* tev = trace_ev ? trace_ev + (size_t)2 * evPer * c : nullptr;
+        int* used = trace_ev_used ? &trace_ev_used[c] : nullptr;
+        if (cp.n_units == 0) { if (used) *used = 0; continue; }
+        auto job = [=, &rc, &iters]() { rc[(size_t)c] = run_cohort(device, sc, cam, cp, b, traceBlocks, h_cnt + 16 * c, cs, tev, evPer, used, drainBelow, &iters[(size_t)c]); };
+        if (C == 1) job(); else th.emplace_back(job);
+    }
+    for (auto& t : th) t.join();
+    for (int c = 0; c < C; c++) if (rc[(size_t)c] != hipSuccess) return rc[(size_t)c];
+    // every cohort stream has been synchronised by its poll loop; order the caller's stream after them anyway
+    for (int c = 1; c < C; c++) {
+        if ((e = hipEventRecord(ev_join[c - 1], xstreams[c - 1])) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(stream, ev_join[c - 1], 0)) != hipSuccess) return e;
+    }
+    if (ev_end) { if ((e = hipEventRecord(ev_end, stream)) != hipSuccess) return e; }
+    int mx = 0; for (int v : iters) mx = v > mx ? v : mx;
+    if (iters_out) *iters_out = mx;
     return hipSuccess;
 }
 
