@@ -261,7 +261,7 @@ void pt_scene_destroy(PtScene* s)
 int32_t pt_scene_num_lights(const PtScene* s) { return s ? s->n_lights : 0; }
 int64_t pt_scene_device_bytes(const PtScene* s) { return s ? s->bytes : 0; }
 
-static const int kTraceBlocks = 2048;   // persistent grid of the traversal kernel: 256 CUs x 8 blocks of 4 waves
+static const int kTraceBlocks = getenv("PTAMD_TB") ? atoi(getenv("PTAMD_TB")) : 2048;   // persistent grid of the traversal kernel: 256 CUs x 8 blocks of 4 waves
 
 // ---- geometry of the tile split --------------------------------------------------------
 static int fill_params(const PtCamera* cam, const PtParams* prm, ptd::DevParams& d)
