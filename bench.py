@@ -86,19 +86,29 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the render path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks
+    # (ranks then share devices and the gather goes through host memory)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- scene (host): every rank builds and uploads its own replica (no collective needed) ----
     t0 = time.time()
     prims = ptamd.gen_scene(1, LAT_LON)
     nodes, tris, depth = ptamd.build_bvh(prims)
     t_build = time.time() - t0
-    scene = ptamd.Scene(nodes, tris, device=local_rank)
+    scene = ptamd.Scene(nodes, tris, device=dev_index)
     cam = ptamd.make_camera(W, H)
 
     def params(first_pass, passes):
@@ -119,20 +129,24 @@ def main():
     if warm is not None:
         warm.render()
         if world > 1:   # warm the collective once as well
-            gather_tiles(warm.tiles, rank, world)
+            gather_tiles(warm.tiles if backend == "nccl" else warm.tiles.cpu(), rank, world)
         del warm
     barrier()
     scene.render_timings(reset=True)
     scene.enable_trace_timing(16384)         # HIP event pair around every wf_trace launch, on the launch stream
     t0 = time.perf_counter()
     tr.render()
-    gathered = gather_tiles(tr.tiles, rank, world)           # the single exchange step
+    if world > 1 and backend != "nccl":                      # rehearsal: gloo gathers host tensors
+        g = gather_tiles(tr.tiles.cpu(), rank, world)
+        gathered = g.to(dev) if rank == 0 else None
+    else:
+        gathered = gather_tiles(tr.tiles, rank, world)       # the single exchange step (RCCL over xGMI)
     if rank == 0:
         frame = tr.assemble(gathered, world)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms = scene.render_timings(reset=True)
