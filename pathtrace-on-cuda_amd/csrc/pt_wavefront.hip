@@ -45,10 +45,12 @@ struct WfCounters {      // one slot per iteration parity (3 rotating slots); ev
     uint32_t nActive, padA[31];
     uint32_t nPath, padB[31];
     uint32_t nShadow, padC[31];
-    uint32_t headPath, padD[15];
-    uint32_t nSusp, padE[15];
+    uint32_t nSusp, padD[31];
+    struct { uint32_t v, pad[31]; } head[16];     // sharded ray-queue heads, one 128-B line each
 };
-static_assert(sizeof(WfCounters) == 512, "counter slot is 512 bytes");
+constexpr int kWfShards = 16;
+constexpr int kWfSlotBytes = 2560;
+static_assert(sizeof(WfCounters) == kWfSlotBytes, "counter slot layout");
 
 struct WfBuf {
     uint4* rng0;         // x0 x1 x2 x3
@@ -186,7 +188,6 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, uint32_
     // one queue index space: [0, nPath) are path rays, [nPath, nPath + nShadow) shadow rays
     const uint32_t nPath = b.cnt[slot].nPath;
     const uint32_t n = nPath + b.cnt[slot].nShadow;
-    uint32_t* head = &b.cnt[slot].headPath;
     if ((uint32_t)blockIdx.x * 256u >= n) return;      // surplus blocks leave before touching the queue
 
     const int lane = threadIdx.x & 63;
@@ -205,6 +206,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, uint32_
     const uint32_t kChunk = (n >> 15) < 16u ? 16u : ((n >> 15) > (uint32_t)kWfChunk ? (uint32_t)kWfChunk : (n >> 15));
 
     uint32_t chunkPos = 0, chunkEnd = 0;   // wave-uniform
+    int shard = (int)(blockIdx.x % kWfShards), shardsTried = 0;   // wave-uniform; blockIdx % 8 shares an XCD, so a shard stays in one L2
     bool exhausted = false;                // wave-uniform
     bool hasRay = false;
     // per-ray registers
@@ -221,11 +223,19 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, uint32_
         const int nIdle = __builtin_popcountll(idle);
         if (!exhausted && (nIdle >= kWfRefill)) {
             if (chunkPos == chunkEnd) {
-                uint32_t start = 0;
-                if (lane == 0) start = atomicAdd(head, kChunk);
-                start = __builtin_amdgcn_readfirstlane(start);
-                if (start >= n) { exhausted = true; }
-                else { chunkPos = start; chunkEnd = (start + kChunk < n) ? start + kChunk : n; }
+                // The queue index space is cut into kWfShards ranges, each with its own head word (a
+                // single word saturates near 88 returning atomics per microsecond, which throttled
+                // launches of a few million rays).  A wave drains its home shard, then helps the next.
+                for (;;) {
+                    const uint32_t lo = (uint32_t)(((unsigned long long)n * (unsigned)shard) / kWfShards);
+                    const uint32_t hi = (uint32_t)(((unsigned long long)n * (unsigned)(shard + 1)) / kWfShards);
+                    uint32_t start = 0;
+                    if (lane == 0) start = atomicAdd(&b.cnt[slot].head[shard].v, kChunk);
+                    start = __builtin_amdgcn_readfirstlane(start);
+                    if (start < hi - lo) { chunkPos = lo + start; chunkEnd = (hi - lo - start > kChunk) ? chunkPos + kChunk : hi; break; }
+                    shard = (shard + 1) % kWfShards;
+                    if (++shardsTried >= kWfShards) { exhausted = true; break; }
+                }
             }
             if (!exhausted) {
                 const uint32_t avail = chunkEnd - chunkPos;
@@ -522,7 +532,7 @@ __global__ __launch_bounds__(256, 4)
 void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, int slotOut, int slotClear, int listIn)
 {
     const uint32_t nIn = b.cnt[slotIn].nActive;
-    if (blockIdx.x == 0 && threadIdx.x < 128) ((uint32_t*)&b.cnt[slotClear])[threadIdx.x] = 0;
+    if (blockIdx.x == 0) for (int k = threadIdx.x; k < kWfSlotBytes / 4; k += 256) ((uint32_t*)&b.cnt[slotClear])[k] = 0;
     if ((uint32_t)blockIdx.x * 256u >= nIn) return;
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     const bool have = idx < nIn;
@@ -615,7 +625,7 @@ static size_t cohort_bytes(size_t nStreams, int traceBlocks)
     b += n16 * 16 * 4;          // ray_o/ray_d x2
     b += n16 * 8 * 2;           // hits
     b += n16 * 4 * 4;           // active x2, rq x2
-    b += 3 * 512;               // counters
+    b += 3 * ptd::kWfSlotBytes; // counters
     b += (size_t)traceBlocks * 256 * ptd::kWfOvfLevels * 4;
     b += 2 * ((nStreams / 4 + 1024) * ptd::kSuspInts * 4 + 16);
     return b + 512;
@@ -655,7 +665,7 @@ static void carve(char* p, size_t nStreams, int traceBlocks, ptd::WfBuf& b)
     for (int k = 0; k < 2; k++) b.hit[k] = (float2*)take(n16 * 8);
     for (int k = 0; k < 2; k++) b.active[k] = (uint32_t*)take(n16 * 4);
     for (int k = 0; k < 2; k++) b.rq[k] = (uint32_t*)take(n16 * 4);
-    b.cnt = (ptd::WfCounters*)take(3 * 512);
+    b.cnt = (ptd::WfCounters*)take(3 * ptd::kWfSlotBytes);
     b.ovf = (int*)take((size_t)traceBlocks * 256 * ptd::kWfOvfLevels * 4);
     b.suspCap = (uint32_t)(nStreams / 4 + 1024);
     for (int k = 0; k < 2; k++) b.susp[k] = (int*)take((size_t)b.suspCap * ptd::kSuspInts * 4);
@@ -673,7 +683,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess) return e;
     const size_t nStreams = (size_t)prm.n_units * 64;
-    if ((e = hipMemsetAsync(b.cnt, 0, 3 * 512, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(b.cnt, 0, 3 * kWfSlotBytes, stream)) != hipSuccess) return e;
     const int nb = (int)((nStreams + 255) / 256);
     hipLaunchKernelGGL(wf_init, dim3(nb), dim3(256), 0, stream, *cam, prm, b, (uint32_t)nStreams);
     const int ovfStride = traceBlocks * 256;
