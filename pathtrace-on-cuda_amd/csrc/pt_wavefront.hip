@@ -75,7 +75,7 @@ struct WfBuf {
 
 constexpr int kWfLdsStack = 16;      // stack entries per lane kept in LDS (4 KB / wave -> 8 waves/SIMD fit)
 constexpr int kWfOvfLevels = 32;     // further levels spill to global memory (never seen on the config scenes)
-constexpr int kWfChunk = 1024;       // most ray ids a wave takes from the global queue per atomic
+constexpr int kWfChunk = 128;        // most ray ids a wave takes from a queue shard per atomic (measured optimum 116-229)
 constexpr int kWfRefill = 16;        // refill lanes once this many are idle
 constexpr int kDone = (int)0x80000000;
 // Time slicing: every launch is followed by a device-wide dependency (the shade kernel needs all
@@ -182,7 +182,7 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
 // closest one.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 8)
-void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, uint32_t latencyBelow)
+void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, uint32_t latencyBelow, int chunkShift)
 {
     __shared__ int lds_stack[4][kWfLdsStack * 64];
     // one queue index space: [0, nPath) are path rays, [nPath, nPath + nShadow) shadow rays
@@ -203,7 +203,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, uint32_
     int* __restrict__ suspOut = b.susp[parity];
     // rays a wave takes per queue access: ~n / (4 x resident waves), between 16 and kWfChunk (one word
     // saturates near 88 returning atomics per microsecond, so large launches take large chunks)
-    const uint32_t kChunk = (n >> 15) < 16u ? 16u : ((n >> 15) > (uint32_t)kWfChunk ? (uint32_t)kWfChunk : (n >> 15));
+    const uint32_t kChunk = (n >> chunkShift) < 16u ? 16u : ((n >> chunkShift) > (uint32_t)kWfChunk ? (uint32_t)kWfChunk : (n >> chunkShift));
 
     uint32_t chunkPos = 0, chunkEnd = 0;   // wave-uniform
     int shard = (int)(blockIdx.x % kWfShards), shardsTried = 0;   // wave-uniform; blockIdx % 8 shares an XCD, so a shard stays in one L2
@@ -691,6 +691,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     // every sample needs at most max_bounce + (max_refract + 2) bounces, +1 iteration to retire
     // (time-sliced rays add iterations; 64x is far beyond anything a finite tree can need)
     const long long hardCap = ((long long)prm.spp_per_pass * (prm.max_bounce + prm.max_refract + 3) + 8) * 64;
+    static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
     static const uint32_t latencyBelow = getenv("PTAMD_LAT") ? (uint32_t)atoll(getenv("PTAMD_LAT")) : 0u;
     int it = 0;
     int poll = 16;
@@ -699,7 +700,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
             const bool timed = trace_ev && it < trace_ev_pairs;
             if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
-            hipLaunchKernelGGL(wf_trace, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, latencyBelow);
+            hipLaunchKernelGGL(wf_trace, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, latencyBelow, chunkShift);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
             hipLaunchKernelGGL(wf_shade, dim3(nb), dim3(256), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
         }
