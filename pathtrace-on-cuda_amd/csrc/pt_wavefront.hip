@@ -99,20 +99,25 @@ PT_DEV void wave_append(bool emit, uint32_t id, uint32_t* counter, uint32_t* lis
     if (emit) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = id;
 }
 
-// block-aggregated append to three lists at once: one atomicAdd per list per 256-thread block.
+// block-aggregated append to three lists at once: one atomicAdd per list per block.
 // (One atomic per wave was the shade kernel's bottleneck: ~100k returning atomics per launch on
-// one cache line serialise at ~88 per microsecond.)  Must be called by all 256 threads.
+// one cache line serialise at ~88 per microsecond; 1024-thread blocks keep it to ~2k per list.)
+// Must be called by every thread of the block.
+constexpr int kShadeThreads = 1024;
 PT_DEV void block_append3(bool e0, bool e1, bool e2, uint32_t id, uint32_t* c0, uint32_t* c1, uint32_t* c2,
                           uint32_t* l0, uint32_t* l1, uint32_t* l2)
 {
-    __shared__ uint32_t s_cnt[3][4];
+    constexpr int W = kShadeThreads / 64;
+    __shared__ uint32_t s_cnt[3][W];
     __shared__ uint32_t s_base[3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = (int)(blockDim.x >> 6);
     const unsigned long long m0 = __ballot(e0), m1 = __ballot(e1), m2 = __ballot(e2);
     if (lane == 0) { s_cnt[0][wave] = __builtin_popcountll(m0); s_cnt[1][wave] = __builtin_popcountll(m1); s_cnt[2][wave] = __builtin_popcountll(m2); }
     __syncthreads();
     if (threadIdx.x < 3) {
-        const uint32_t tot = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
+        uint32_t tot = 0;
+        for (int w = 0; w < nw; w++) tot += s_cnt[threadIdx.x][w];
         uint32_t* c = threadIdx.x == 0 ? c0 : (threadIdx.x == 1 ? c1 : c2);
         s_base[threadIdx.x] = tot ? atomicAdd(c, tot) : 0u;
     }
@@ -528,13 +533,13 @@ PT_DEV void write_mean(const WfBuf& b, const DevParams& prm, uint32_t sid, const
 // ---------------------------------------------------------------------------------------
 // wf_shade: one thread per live stream, one bounce.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4)
+__global__ __launch_bounds__(kShadeThreads, 4)
 void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, int slotOut, int slotClear, int listIn)
 {
     const uint32_t nIn = b.cnt[slotIn].nActive;
-    if (blockIdx.x == 0) for (int k = threadIdx.x; k < kWfSlotBytes / 4; k += 256) ((uint32_t*)&b.cnt[slotClear])[k] = 0;
-    if ((uint32_t)blockIdx.x * 256u >= nIn) return;
-    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (blockIdx.x == 0) for (int k = threadIdx.x; k < kWfSlotBytes / 4; k += kShadeThreads) ((uint32_t*)&b.cnt[slotClear])[k] = 0;
+    if ((uint32_t)blockIdx.x * (uint32_t)kShadeThreads >= nIn) return;
+    const uint32_t idx = blockIdx.x * (uint32_t)kShadeThreads + threadIdx.x;
     const bool have = idx < nIn;
     bool emitPath = false, emitShadow = false, alive = false;
     uint32_t sid = 0;
@@ -702,7 +707,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
             hipLaunchKernelGGL(wf_trace, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, latencyBelow, chunkShift);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
-            hipLaunchKernelGGL(wf_shade, dim3(nb), dim3(256), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
+            hipLaunchKernelGGL(wf_shade, dim3((nb * 256 + kShadeThreads - 1) / kShadeThreads), dim3(kShadeThreads), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(h_cnt, &b.cnt[it % 3].nActive, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
