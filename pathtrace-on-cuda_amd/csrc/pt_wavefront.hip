@@ -6,18 +6,19 @@
 // holds 190 VGPRs (2 waves/SIMD).  Here every (pixel, pass) is a *stream* whose state lives
 // in HBM as SoA float4 arrays; each iteration advances every live stream by one bounce:
 //
-//   wf_trace<PATH>    closest hits of all pending path rays      } lean kernel, 8 waves/SIMD,
-//   wf_trace<SHADOW>  visibility of all pending NEE shadow rays  } lanes refill from the queue
-//   wf_shade          apply NEE, shade the path hit, draw the bounce's random numbers, emit the
-//                     next shadow ray + path ray (or the next sample's camera ray), or retire
-//                     the stream and write its per-pass mean.
+//   wf_trace  closest hits of all pending path rays and visibility of all pending NEE shadow
+//             rays (one queue index space): lean kernel, 8 waves/SIMD, lanes refill from the queue
+//   wf_shade  apply NEE, shade the path hit, draw the bounce's random numbers, emit the next
+//             shadow ray + path ray (or the next sample's camera ray), or retire the stream and
+//             write its per-pass mean.
 //
-// The traversal kernel is persistent: a wave takes ray ids from a global queue in chunks and,
-// whenever >= 16 of its lanes have finished their ray, hands them new ones (ballot + mbcnt
-// compaction), so lanes do not idle for the longest ray of the wave.  Each trip of its loop
-// advances every lane by one unit — a node step or one triangle test ("if-if") — so no lane
-// waits for another lane's subtree walk.  Shadow rays stop at the first hit that is provably in front of the
-// sampled light point (result-neutral, see wf_trace).
+// The traversal kernel is persistent: a wave takes ray ids from a 16-way sharded queue in
+// chunks of <= 128 and, whenever >= 16 of its lanes have finished their ray, hands them new
+// ones (ballot + prefix-popcount compaction), so lanes do not idle for the longest ray of the
+// wave.  Each trip of its loop the wave votes between a node step and a triangle test, so only
+// one code path runs and it serves the majority.  Rays that exceed a node budget are suspended
+// and resumed by the next launch (time slicing).  Shadow rays stop at the first hit that is
+// provably in front of the sampled light point (result-neutral, see wf_trace).
 //
 // Per-stream arithmetic — order of random draws, every float operation — is exactly that of
 // render_units / the reference's GetColor_iter, so images are bit-identical across modes.
@@ -85,19 +86,6 @@ constexpr int kDone = (int)0x80000000;
 // launch resumes it.  hit.prim <= -2 encodes "pending, record = -2 - prim".
 constexpr int kWfBudget = 96;         // node steps per launch when the launch is throughput-bound
 constexpr int kSuspInts = 4 + kWfLdsStack + kWfOvfLevels;
-
-// wave-aggregated append of one id per participating lane
-PT_DEV void wave_append(bool emit, uint32_t id, uint32_t* counter, uint32_t* list)
-{
-    const unsigned long long m = __ballot(emit);
-    if (m == 0ull) return;
-    uint32_t base = 0;
-    const int lane = threadIdx.x & 63;
-    const int leader = __builtin_ctzll(m);
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
-    base = __shfl(base, leader);
-    if (emit) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = id;
-}
 
 // block-aggregated append to three lists at once: one atomicAdd per list per block.
 // (One atomic per wave was the shade kernel's bottleneck: ~100k returning atomics per launch on
@@ -187,7 +175,7 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
 // closest one.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 8)
-void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, uint32_t latencyBelow, int chunkShift)
+void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift)
 {
     __shared__ int lds_stack[4][kWfLdsStack * 64];
     // one queue index space: [0, nPath) are path rays, [nPath, nPath + nShadow) shadow rays
@@ -201,9 +189,6 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, uint32_
     // node steps a ray may take in this launch before it is suspended: large launches hide long rays,
     // small (latency-bound) launches must not wait for them
     const int budget = (n >> 15) < (uint32_t)kWfBudget ? kWfBudget : ((n >> 15) > 1024u ? 1024 : (int)(n >> 15));
-    // few rays: the launch is bound by the slowest wave's dependent chain, not by issue slots, so let every
-    // lane advance each trip (both code paths run); many rays: vote, one path per trip
-    const bool latencyBound = n < latencyBelow;
     const int* __restrict__ suspIn = b.susp[parity ^ 1];
     int* __restrict__ suspOut = b.susp[parity];
     // rays a wave takes per queue access: ~n / (4 x resident waves), between 16 and kWfChunk (one word
@@ -308,8 +293,8 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, uint32_
             // wave vote: run ONE of the two code paths this trip — the one more lanes are waiting for
             const int nNode = __builtin_popcountll(__ballot(cur >= 0));
             const int nTri = __builtin_popcountll(__ballot(hasRay && cur < 0 && cur != kDone));
-            const bool doNode = latencyBound || nNode >= nTri;
-            const bool doTri = latencyBound || !doNode;
+            const bool doNode = nNode >= nTri;
+            const bool doTri = !doNode;
             if (doNode && cur >= 0) {
                 steps++;
                 const float4 q0 = sc.nodes[4 * cur + 0];
@@ -637,17 +622,17 @@ static size_t cohort_bytes(size_t nStreams, int traceBlocks)
 }
 static size_t staging_bytes(size_t nStreams) { return ((nStreams * 12 + 16) + 255) & ~(size_t)255; }
 
-// Streams are split into cohorts that run the pipeline concurrently on separate HIP streams
-// (pt_wavefront's per-iteration launches each end in a latency-bound tail; another cohort's
-// kernels fill it, and a cohort's bandwidth-bound shade kernel overlaps another's issue-bound
-// trace kernel).  Cohorts are contiguous unit ranges, so each is a whole number of (tile, pass) units.
+// Streams can be split into cohorts that run the pipeline concurrently on separate HIP streams
+// (contiguous unit ranges, so each is a whole number of (tile, pass) units).  Measured on MI355X:
+// before the queue heads were sharded two cohorts gained 8 % on 16.6M streams (one cohort's
+// shade kernel overlapping the other's trace kernel); with sharded heads one cohort is as fast
+// (927 vs 920 Msamples/s) and small renders lose, so the default is one.  PTAMD_COHORTS=2..4
+// turns it on for experiments.
 int ptk_wf_cohorts(size_t nUnits)
 {
     static const int forced = getenv("PTAMD_COHORTS") ? atoi(getenv("PTAMD_COHORTS")) : 0;
-    int c = forced > 0 ? forced : (int)(nUnits * 64 / (8u << 20));     // measured: 2 cohorts pay off from ~8M streams, hurt below
-    if (forced <= 0 && c > 2) c = 2;
+    int c = forced > 0 ? forced : 1;
     if (c > 4) c = 4;
-    if (c < 1) c = 1;
     if ((size_t)c > nUnits) c = (int)(nUnits ? nUnits : 1);
     return c;
 }
@@ -697,7 +682,6 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     // (time-sliced rays add iterations; 64x is far beyond anything a finite tree can need)
     const long long hardCap = ((long long)prm.spp_per_pass * (prm.max_bounce + prm.max_refract + 3) + 8) * 64;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
-    static const uint32_t latencyBelow = getenv("PTAMD_LAT") ? (uint32_t)atoll(getenv("PTAMD_LAT")) : 0u;
     int it = 0;
     int poll = 16;
     for (;;) {
@@ -705,7 +689,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
             const bool timed = trace_ev && it < trace_ev_pairs;
             if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
-            hipLaunchKernelGGL(wf_trace, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, latencyBelow, chunkShift);
+            hipLaunchKernelGGL(wf_trace, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
             hipLaunchKernelGGL(wf_shade, dim3((nb * 256 + kShadeThreads - 1) / kShadeThreads), dim3(kShadeThreads), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
         }
