@@ -84,7 +84,7 @@ constexpr int kDone = (int)0x80000000;
 // ~800 us per launch).  A ray that has visited kWfBudget nodes is therefore suspended — cur, sp,
 // closest hit and stack go to a record — and its stream simply waits one iteration; the next
 // launch resumes it.  hit.prim <= -2 encodes "pending, record = -2 - prim".
-constexpr int kWfBudget = 96;         // node steps per launch when the launch is throughput-bound
+constexpr int kWfBudget = 256;        // least node steps a ray may take per launch (measured: 96 cost 8 % on a 2M-stream render, >= 192 is flat)
 constexpr int kSuspInts = 4 + kWfLdsStack + kWfOvfLevels;
 
 // block-aggregated append to three lists at once: one atomicAdd per list per block.
@@ -175,7 +175,7 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
 // closest one.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 8)
-void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift)
+void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin)
 {
     __shared__ int lds_stack[4][kWfLdsStack * 64];
     // one queue index space: [0, nPath) are path rays, [nPath, nPath + nShadow) shadow rays
@@ -188,7 +188,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
     int* ovf = b.ovf + (blockIdx.x * 256 + threadIdx.x);
     // node steps a ray may take in this launch before it is suspended: large launches hide long rays,
     // small (latency-bound) launches must not wait for them
-    const int budget = (n >> 15) < (uint32_t)kWfBudget ? kWfBudget : ((n >> 15) > 1024u ? 1024 : (int)(n >> 15));
+    const int budget = (n >> budgetShift) < (uint32_t)budgetMin ? budgetMin : ((n >> budgetShift) > 1024u ? 1024 : (int)(n >> budgetShift));
     const int* __restrict__ suspIn = b.susp[parity ^ 1];
     int* __restrict__ suspOut = b.susp[parity];
     // rays a wave takes per queue access: ~n / (4 x resident waves), between 16 and kWfChunk (one word
@@ -681,6 +681,8 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     // every sample needs at most max_bounce + (max_refract + 2) bounces, +1 iteration to retire
     // (time-sliced rays add iterations; 64x is far beyond anything a finite tree can need)
     const long long hardCap = ((long long)prm.spp_per_pass * (prm.max_bounce + prm.max_refract + 3) + 8) * 64;
+    static const int budgetShift = getenv("PTAMD_BS") ? atoi(getenv("PTAMD_BS")) : 14;
+    static const int budgetMin = getenv("PTAMD_BM") ? atoi(getenv("PTAMD_BM")) : kWfBudget;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
     int it = 0;
     int poll = 16;
@@ -689,7 +691,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
             const bool timed = trace_ev && it < trace_ev_pairs;
             if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
-            hipLaunchKernelGGL(wf_trace, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift);
+            hipLaunchKernelGGL(wf_trace, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
             hipLaunchKernelGGL(wf_shade, dim3((nb * 256 + kShadeThreads - 1) / kShadeThreads), dim3(kShadeThreads), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
         }
