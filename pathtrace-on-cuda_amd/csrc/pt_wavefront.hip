@@ -175,7 +175,7 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
 // closest one.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 8)
-void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin)
+void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift)
 {
     __shared__ int lds_stack[4][kWfLdsStack * 64];
     // one queue index space: [0, nPath) are path rays, [nPath, nPath + nShadow) shadow rays
@@ -196,6 +196,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
     const uint32_t kChunk = (n >> chunkShift) < 16u ? 16u : ((n >> chunkShift) > (uint32_t)kWfChunk ? (uint32_t)kWfChunk : (n >> chunkShift));
 
     uint32_t chunkPos = 0, chunkEnd = 0;   // wave-uniform
+    uint32_t seenLeft = 0xffffffffu;       // rays this wave last saw left in its current shard (wave-uniform)
     int shard = (int)(blockIdx.x % kWfShards), shardsTried = 0;   // wave-uniform; blockIdx % 8 shares an XCD, so a shard stays in one L2
     bool exhausted = false;                // wave-uniform
     bool hasRay = false;
@@ -219,10 +220,15 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 for (;;) {
                     const uint32_t lo = (uint32_t)(((unsigned long long)n * (unsigned)shard) / kWfShards);
                     const uint32_t hi = (uint32_t)(((unsigned long long)n * (unsigned)(shard + 1)) / kWfShards);
+                    // guided self-scheduling: the chunk shrinks with what this wave last saw left in the shard, so the
+                    // last rays of a launch are spread over many waves instead of queuing behind one
+                    uint32_t want = seenLeft >> guideShift;
+                    want = want < 16u ? 16u : (want > kChunk ? kChunk : want);
                     uint32_t start = 0;
-                    if (lane == 0) start = atomicAdd(&b.cnt[slot].head[shard].v, kChunk);
+                    if (lane == 0) start = atomicAdd(&b.cnt[slot].head[shard].v, want);
                     start = __builtin_amdgcn_readfirstlane(start);
-                    if (start < hi - lo) { chunkPos = lo + start; chunkEnd = (hi - lo - start > kChunk) ? chunkPos + kChunk : hi; break; }
+                    if (start < hi - lo) { chunkPos = lo + start; chunkEnd = (hi - lo - start > want) ? chunkPos + want : hi; seenLeft = hi - lo - start; break; }
+                    seenLeft = 0xffffffffu;
                     shard = (shard + 1) % kWfShards;
                     if (++shardsTried >= kWfShards) { exhausted = true; break; }
                 }
@@ -681,6 +687,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     // every sample needs at most max_bounce + (max_refract + 2) bounces, +1 iteration to retire
     // (time-sliced rays add iterations; 64x is far beyond anything a finite tree can need)
     const long long hardCap = ((long long)prm.spp_per_pass * (prm.max_bounce + prm.max_refract + 3) + 8) * 64;
+    static const int guideShift = getenv("PTAMD_GS") ? atoi(getenv("PTAMD_GS")) : 9;
     static const int budgetShift = getenv("PTAMD_BS") ? atoi(getenv("PTAMD_BS")) : 14;
     static const int budgetMin = getenv("PTAMD_BM") ? atoi(getenv("PTAMD_BM")) : kWfBudget;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
@@ -691,7 +698,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
             const bool timed = trace_ev && it < trace_ev_pairs;
             if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
-            hipLaunchKernelGGL(wf_trace, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin);
+            hipLaunchKernelGGL(wf_trace, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
             hipLaunchKernelGGL(wf_shade, dim3((nb * 256 + kShadeThreads - 1) / kShadeThreads), dim3(kShadeThreads), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
         }
