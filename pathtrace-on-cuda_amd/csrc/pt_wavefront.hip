@@ -687,6 +687,11 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     // every sample needs at most max_bounce + (max_refract + 2) bounces, +1 iteration to retire
     // (time-sliced rays add iterations; 64x is far beyond anything a finite tree can need)
     const long long hardCap = ((long long)prm.spp_per_pass * (prm.max_bounce + prm.max_refract + 3) + 8) * 64;
+    // Scheduling constants of wf_trace.  Each has an environment override used for the sweeps recorded in
+    // DESIGN.md section 5.4 (tuning only — none of them can change a result):
+    //   PTAMD_CS  chunk  = clamp(n >> CS, 16, kWfChunk) ray ids per queue access        (default 12)
+    //   PTAMD_GS  guided = chunk shrinks to (rays left in the shard) >> GS              (default 9)
+    //   PTAMD_BS / PTAMD_BM  node budget = clamp(n >> BS, BM, 1024) steps per launch    (default 14 / 256)
     static const int guideShift = getenv("PTAMD_GS") ? atoi(getenv("PTAMD_GS")) : 9;
     static const int budgetShift = getenv("PTAMD_BS") ? atoi(getenv("PTAMD_BS")) : 14;
     static const int budgetMin = getenv("PTAMD_BM") ? atoi(getenv("PTAMD_BM")) : kWfBudget;
