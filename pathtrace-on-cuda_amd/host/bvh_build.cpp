@@ -13,12 +13,19 @@
 //     (same libstdc++ introsort on the same input).
 //   * the split is the reference's cumulative-triangle-area cost
 //     `CSA[i-1]*i + (total-CSA[i-1])*(n-i)`, first minimum wins (bvh.cpp:467-477).
+//   * the sort+split recursion runs first and in parallel across subtrees (siblings are independent;
+//     every std::sort call still sees exactly the sequence the sequential build would give it), the
+//     emission pass that follows is serial and only reads the recorded split positions;
 //   * nodes are emitted directly in the flattened order: LoadFromBVH pops Child[1] before
 //     Child[0], so the array is a pre-order in which childL = Child[1] = index+1.
 //     Boxes are filled in on the way back up (leaf: over the three vertices of each
 //     primitive, bvh.cpp:400-406; interior: union of the children, bvh.cpp:505-506).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <future>
+#include <thread>
+#include <unordered_map>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -41,8 +48,9 @@ struct Builder {
     std::vector<unsigned> idx;          // working index array (the reference's Cluster::primitives, concatenated)
     std::vector<float> key[3];          // centroid per axis
     std::vector<float> area;            // |cross(v2-v1, v3-v1)| (not halved, bvh.cpp:460)
-    std::vector<float> csa;
     PtFlatBVH* out;
+    std::unordered_map<unsigned long long, int> splitOf;   // (lo,hi) -> split, filled by sort_split
+    std::vector<PtTriangle> flat;       // flattened triangle per primitive id (filled in parallel)
 
     static inline float min2(float x, float y) { return (y < x) ? y : x; }   // glm::min
     static inline float max2(float x, float y) { return (x < y) ? y : x; }   // glm::max
@@ -52,7 +60,6 @@ struct Builder {
         idx.resize((size_t)n);
         for (int a = 0; a < 3; a++) key[a].resize((size_t)n);
         area.resize((size_t)n);
-        csa.resize((size_t)n);
         for (int i = 0; i < n; i++) {
             idx[(size_t)i] = (unsigned)i;
             const PtVec3 &p1 = prims[i].v1.Position, &p2 = prims[i].v2.Position, &p3 = prims[i].v3.Position;
@@ -67,7 +74,53 @@ struct Builder {
         }
     }
 
-    // Emits the subtree over idx[lo,hi) and returns its node index.
+    typedef std::vector<std::pair<unsigned long long, int>> SplitList;
+    static unsigned long long key_of(int lo, int hi) { return ((unsigned long long)(unsigned)lo << 32) | (unsigned)hi; }
+
+    // Phase 1: sort + split of idx[lo,hi) and, recursively, of its two halves (bvh.cpp:439-494).
+    // Large subtrees near the root are handed to other threads.
+    void sort_split(int lo, int hi, int axis, int depth, SplitList& rec, std::vector<float>& csa)
+    {
+        const int cnt = hi - lo;
+        if (cnt <= 4) return;                                             // stopNumber, bvh.h:128 / bvh.cpp:441
+        const float* k = key[axis].data();
+        std::sort(idx.begin() + lo, idx.begin() + hi, [k](const unsigned A, const unsigned B) { return k[A] > k[B]; });   // bvh.cpp:451-454
+        if ((int)csa.size() < cnt) csa.resize((size_t)cnt);
+        for (int i = 0; i < cnt; i++) {
+            const float a = area[idx[(size_t)(lo + i)]];
+            csa[(size_t)i] = (i > 0) ? csa[(size_t)(i - 1)] + a : a;
+        }
+        float minValue = std::numeric_limits<float>::max();
+        int split = 0;
+        for (int i = 1; i < cnt; i++) {
+            const float fi = csa[(size_t)(i - 1)] * i + (csa[(size_t)(cnt - 1)] - csa[(size_t)(i - 1)]) * (cnt - i);
+            if (fi < minValue) { minValue = fi; split = i; }
+        }
+        rec.emplace_back(key_of(lo, hi), split);
+        const int next = (axis + 1) % 3;
+        if (depth < 4 && cnt > 16384 && std::thread::hardware_concurrency() > 1) {
+            SplitList other;
+            auto fut = std::async(std::launch::async, [&, this]() { std::vector<float> c2; sort_split(lo + split, hi, next, depth + 1, other, c2); });
+            sort_split(lo, lo + split, next, depth + 1, rec, csa);
+            fut.get();
+            rec.insert(rec.end(), other.begin(), other.end());
+        } else {
+            sort_split(lo + split, hi, next, depth + 1, rec, csa);
+            sort_split(lo, lo + split, next, depth + 1, rec, csa);
+        }
+    }
+
+    void flatten_all()
+    {
+        flat.resize((size_t)n);
+        const unsigned nt = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([this, t, nt]() { for (int i = (int)t; i < n; i += (int)nt) flat[(size_t)i] = flatten_tri(prims[i]); });
+        for (auto& x : th) x.join();
+    }
+
+    // Phase 2: emits the subtree over idx[lo,hi) (already ordered by phase 1) and returns its node index.
     int build(int lo, int hi, int axis, int depth)
     {
         const int me = (int)out->nodes.size();
@@ -85,7 +138,7 @@ struct Builder {
                     mn[d] = min2(mn[d], min2(a[d], min2(b[d], c[d])));
                     mx[d] = max2(mx[d], max2(a[d], max2(b[d], c[d])));
                 }
-                out->tris.push_back(flatten_tri(p));
+                out->tris.push_back(flat[idx[(size_t)k]]);
             }
             PtBVHNode& nd = out->nodes[(size_t)me];
             memcpy(nd.bMin, mn, 12); memcpy(nd.bMax, mx, 12);
@@ -93,19 +146,7 @@ struct Builder {
             nd.primStart = first; nd.primEnd = first + cnt - 1;
             return me;
         }
-        // sort descending by centroid[axis] (bvh.cpp:451-454)
-        const float* k = key[axis].data();
-        std::sort(idx.begin() + lo, idx.begin() + hi, [k](const unsigned A, const unsigned B) { return k[A] > k[B]; });
-        for (int i = 0; i < cnt; i++) {
-            const float a = area[idx[(size_t)(lo + i)]];
-            csa[(size_t)i] = (i > 0) ? csa[(size_t)(i - 1)] + a : a;
-        }
-        float minValue = std::numeric_limits<float>::max();
-        int split = 0;
-        for (int i = 1; i < cnt; i++) {
-            const float fi = csa[(size_t)(i - 1)] * i + (csa[(size_t)(cnt - 1)] - csa[(size_t)(i - 1)]) * (cnt - i);
-            if (fi < minValue) { minValue = fi; split = i; }
-        }
+        const int split = splitOf.at(key_of(lo, hi));
         // Children[0] = idx[lo, lo+split), Children[1] = the rest.  The flattened array holds
         // Child[1]'s subtree first (childL), then Child[0]'s (childR).
         const int next = (axis + 1) % 3;
@@ -170,6 +211,14 @@ int pt_bvh_build_sah(const PtPrimitive* prims, int32_t n_prims, PtFlatBVH** out)
     Builder bl;
     bl.prims = prims; bl.n = n_prims; bl.out = b;
     bl.prepare();
+    {
+        Builder::SplitList rec; std::vector<float> csa;
+        std::thread fl([&bl]() { bl.flatten_all(); });           // independent of the sorting
+        bl.sort_split(0, n_prims, 0, 0, rec, csa);
+        fl.join();
+        bl.splitOf.reserve(rec.size() * 2);
+        for (auto& kv : rec) bl.splitOf.emplace(kv.first, kv.second);
+    }
     bl.build(0, n_prims, 0, 0);
     *out = b;
     return PT_OK;
