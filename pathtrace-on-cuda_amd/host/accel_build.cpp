@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -146,6 +147,7 @@ void pt_build_accel(const PtBVHNode* rnodes, int n_rnodes, const PtTriangle* tri
     }
 
     Builder b;
+    if (const char* e = getenv("PTAMD_LEAF")) { const int v = atoi(e); if (v >= 1 && v <= 7) b.maxLeaf = v; }   // tuning only
     b.items.resize((size_t)n_tris);
     for (int i = 0; i < n_tris; i++) {
         const PtTriangle& t = tris[i];
