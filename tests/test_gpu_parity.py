@@ -309,3 +309,16 @@ def test_config4_full_frame_nan_pixels_are_the_references():
         assert same_bits_or_nan(img[y, x - 1:x + 2], ref[y, x - 1:x + 2]).all()
         assert np.isnan(ref[y, x]).all() and np.isfinite(ref[y, x - 1]).all()
     assert np.array_equal(ptamd.tonemap_u8(img[213:214, 645:646], 1), np.zeros((1, 1, 3), np.uint8))   # NaN -> black
+
+
+def test_tiny_scenes_single_leaf_tree():
+    """Trees whose root is a leaf (<= 4 triangles) and whose only geometry is the light."""
+    cornell = ptamd.gen_scene(0)
+    for prims in (cornell[10:12], cornell[8:12], cornell[[0, 1, 10, 11, 4]]):
+        nodes, tris, _ = ptamd.build_bvh(prims)
+        W, H = 40, 24
+        img_o, _ = O.Scene(nodes.tobytes(), tris).render(O.make_camera(W, H), O.make_params(W, H, 2, 4), 4)
+        sc = ptamd.Scene(nodes, tris)
+        for mode in (1, 0):
+            sc.set_mode(mode)
+            _check_image(sc.render(ptamd.make_camera(W, H), ptamd.default_params(passes=2, spp_per_pass=4)), img_o, f"{len(prims)} tris mode {mode}")
