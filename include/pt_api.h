@@ -210,8 +210,9 @@ PT_API int  pt_dbg_math(int32_t device, const float* in, int32_t n, float* out8)
  * [5] camera paths [6] loop trips of the wave scheduler [7] lane-trips with an active ray */
 PT_API int  pt_last_counters(PtScene* s, int64_t* out8);
 /* Render path: 1 = queue-driven wavefront pipeline (default: traversal and shading are
- * separate kernels, lanes refill from a ray queue), 0 = the one-kernel state machine.
- * Both produce bit-identical frames.  Environment PTAMD_MODE overrides the default.
+ * separate kernels, lanes refill from a ray queue), 0 = the one-kernel state machine,
+ * 2 = one persistent launch of workgroup-local pipelines (experimental, slower).
+ * All produce bit-identical frames.  Environment PTAMD_MODE overrides the default.
  * pt_last_iterations: bounce iterations the pipeline needed for the last render. */
 PT_API int  pt_set_mode(PtScene* s, int32_t mode);
 /* Per-launch timing of the traversal kernel (wf_trace, mode 1): pt_enable_trace_timing makes
