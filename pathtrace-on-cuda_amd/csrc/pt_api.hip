@@ -50,8 +50,8 @@ void pt_set_error(const char* fmt, ...);   // pt_host.cpp
 struct PtScene {
     int device = 0;
     ptd::DevScene dev{};
-    void* d_nodes = nullptr; void* d_tri = nullptr; void* d_tri_ref = nullptr; void* d_leafbox = nullptr;
-    void* d_shade = nullptr; void* d_mats = nullptr;
+    void* d_nodes = nullptr; void* d_quad = nullptr; void* d_tri = nullptr; void* d_leafbox = nullptr;
+    void* d_surf = nullptr;
     void* d_lights = nullptr; void* d_spheres = nullptr;
     unsigned int* d_unit_counter = nullptr;
     void* d_counters = nullptr;
@@ -168,31 +168,18 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     max_depth = accel.depth;
     n_wide = accel.n_wide;
 
-    // ---- triangles: test records, shade records, de-duplicated materials, lights ----
-    std::vector<float> tri((size_t)n_tris * 12), shade((size_t)n_tris * 28), mats, lights;   // tri: reference order (shading)
-    std::map<std::string, int> matIndex;
+    // ---- triangles: surface records (reference order), lights ----
+    std::vector<float> surf((size_t)n_tris * 48), lights;
     int n_lights = 0;
     for (int i = 0; i < n_tris; i++) {
         const PtTriangle& t = tris[i];
-        float* a = &tri[(size_t)i * 12];
-        a[0] = t.V0[0]; a[1] = t.V0[1]; a[2] = t.V0[2]; a[3] = 0.f;
-        a[4] = t.E1[0]; a[5] = t.E1[1]; a[6] = t.E1[2]; a[7] = 0.f;
-        a[8] = t.E2[0]; a[9] = t.E2[1]; a[10] = t.E2[2]; a[11] = 0.f;
-        float* s = &shade[(size_t)i * 28];
-        const float* src[9] = {t.N0, t.N1, t.N2, t.T0, t.T1, t.T2, t.B0, t.B1, t.B2};
-        for (int k = 0; k < 9; k++) { s[3 * k] = src[k][0]; s[3 * k + 1] = src[k][1]; s[3 * k + 2] = src[k][2]; }
-        std::string key((const char*)&t.mat0, sizeof(PtMaterial));
-        auto it = matIndex.find(key);
-        int mi;
-        if (it == matIndex.end()) {
-            mi = (int)matIndex.size();
-            matIndex[key] = mi;
-            const PtMaterial& m = t.mat0;       // Triangle::hit copies mat0 only (CudaPrimitive.cuh:149-154)
-            const float rec[12] = {m.emittance[0], m.emittance[1], m.emittance[2], m.albedo[0], m.albedo[1], m.albedo[2],
-                                   m.specular[0], m.specular[1], m.specular[2], m.opacity, m.roughness, m.metallic};
-            mats.insert(mats.end(), rec, rec + 12);
-        } else mi = it->second;
-        s[27] = as_float(mi);
+        float* a = &surf[(size_t)i * 48];
+        const float* src[12] = {t.V0, t.E1, t.E2, t.N0, t.N1, t.N2, t.T0, t.T1, t.T2, t.B0, t.B1, t.B2};
+        for (int k = 0; k < 12; k++) { a[3 * k] = src[k][0]; a[3 * k + 1] = src[k][1]; a[3 * k + 2] = src[k][2]; }
+        const PtMaterial& m = t.mat0;           // Triangle::hit copies mat0 only (CudaPrimitive.cuh:149-154)
+        const float rec[12] = {m.emittance[0], m.emittance[1], m.emittance[2], m.albedo[0], m.albedo[1], m.albedo[2],
+                               m.specular[0], m.specular[1], m.specular[2], m.opacity, m.roughness, m.metallic};
+        memcpy(a + 36, rec, sizeof(rec));
         auto len = [](const float* e) { return std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]); };
         if (len(t.mat0.emittance) > 0.0001f || len(t.mat1.emittance) > 0.0001f || len(t.mat2.emittance) > 0.0001f) {
             const float rec[16] = {t.V0[0], t.V0[1], t.V0[2], t.V1[0], t.V1[1], t.V1[2], t.V2[0], t.V2[1], t.V2[2],
@@ -216,11 +203,10 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     sc->max_depth = max_depth;
     int rc;
     if ((rc = upload(&sc->d_nodes, accel.wide.data(), accel.wide.size() * 4, sc->bytes)) ||
+        (rc = upload(&sc->d_quad, accel.quad.data(), accel.quad.size() * 4, sc->bytes)) ||
         (rc = upload(&sc->d_tri, accel.tri.data(), accel.tri.size() * 4, sc->bytes)) ||
-        (rc = upload(&sc->d_tri_ref, tri.data(), tri.size() * 4, sc->bytes)) ||
         (rc = upload(&sc->d_leafbox, accel.leafbox.data(), accel.leafbox.size() * 4, sc->bytes)) ||
-        (rc = upload(&sc->d_shade, shade.data(), shade.size() * 4, sc->bytes)) ||
-        (rc = upload(&sc->d_mats, mats.data(), mats.size() * 4, sc->bytes)) ||
+        (rc = upload(&sc->d_surf, surf.data(), surf.size() * 4, sc->bytes)) ||
         (rc = upload(&sc->d_lights, lights.data(), lights.size() * 4, sc->bytes)) ||
         (rc = upload(&sc->d_spheres, sph.data(), sph.size() * 4, sc->bytes))) {
         pt_scene_destroy(sc);
@@ -239,9 +225,8 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     sc->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    sc->dev.nodes = (const float4*)sc->d_nodes; sc->dev.tri = (const float4*)sc->d_tri;
-    sc->dev.tri_ref = (const float4*)sc->d_tri_ref; sc->dev.leafbox = (const float4*)sc->d_leafbox;
-    sc->dev.shade = (const float4*)sc->d_shade; sc->dev.mats = (const float4*)sc->d_mats;
+    sc->dev.nodes = (const float4*)sc->d_nodes; sc->dev.quad = (const uint4*)sc->d_quad; sc->dev.tri = (const float4*)sc->d_tri;
+    sc->dev.leafbox = (const float4*)sc->d_leafbox; sc->dev.surf = (const float4*)sc->d_surf;
     sc->dev.lights = (const float4*)sc->d_lights; sc->dev.spheres = (const float4*)sc->d_spheres;
     sc->dev.n_nodes = n_wide; sc->dev.n_tris = n_tris; sc->dev.n_lights = n_lights; sc->dev.n_spheres = n_spheres;
     *out = sc;
@@ -252,7 +237,7 @@ void pt_scene_destroy(PtScene* s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* p[] = {s->d_nodes, s->d_tri, s->d_tri_ref, s->d_leafbox, s->d_shade, s->d_mats, s->d_lights, s->d_spheres, s->d_unit_counter, s->d_counters};
+    void* p[] = {s->d_nodes, s->d_quad, s->d_tri, s->d_leafbox, s->d_surf, s->d_lights, s->d_spheres, s->d_unit_counter, s->d_counters};
     for (void* q : p) if (q) (void)hipFree(q);
     for (int i = 0; i < PtScene::kEvRing; i++) for (int j = 0; j < 2; j++) if (s->ev[i][j]) (void)hipEventDestroy(s->ev[i][j]);
     if (s->h_poll) (void)hipHostFree(s->h_poll);

@@ -13,12 +13,23 @@
 //        q3 = refL refR (int bits) | unused | unused
 //      ref >= 0 : index of the child's own wide node
 //      ref <  0 : leaf, ~ref = (primStart << 3) | primCount   (primCount 0 = "no child")
+//  quad node (64 B, 16 dwords) — the 4-wide collapse of the same tree, walked by wf_trace.  Child boxes are
+//      quantised to 8 bits per coordinate against the node's origin and per-axis power-of-two scale,
+//      rounded outward (host/accel_build.cpp):
+//        d0..2  origin.xyz (float)      d3  ex | ey<<8 | ez<<16 (int8 exponents: scale = 2^e)
+//        d4..7  child refs (same encoding as above; ~0 = no child, its box is inverted)
+//        d8..10 lo.x lo.y lo.z          d11..13 hi.x hi.y hi.z   (byte k of each dword = child k)
+//      child box = origin + scale * q
 //  tri test record (48 B, 3 x float4):  (V0,prim) (E1,refLeaf) (E2,0) — all a triangle test reads;
 //      prim = index in the reference's order (tie rule, shading), refLeaf = its reference leaf
 //  reference leaf box (32 B): bMin bMax — read only when Triangle::hit accepts (exact acceptance)
-//  tri shade record (112 B, 7 x float4): N0 N1 N2 T0 T1 T2 B0 B1 B2 (27 f) + material index
-//      read once per accepted closest hit
-//  material (48 B, 3 x float4): emittance albedo specular opacity roughness metallic
+//  surface record (192 B, 12 x float4), indexed by primitive in the REFERENCE's order — everything
+//      shading needs about a hit triangle in ONE fetch level (no index chasing: the shade kernel
+//      is bound by the depth of its dependent-load chain, not by bytes):
+//        floats  0.. 8  V0 E1 E2          (u,v are recomputed with the traversal's own operations)
+//        floats  9..35  N0 N1 N2 T0 T1 T2 B0 B1 B2
+//        floats 36..47  mat0: emittance albedo specular opacity roughness metallic
+//      (Triangle::hit copies mat0 only, CudaPrimitive.cuh:149-154)
 //  light (64 B, 4 x float4): V0 V1 V2 normal area (13 f)            — srcs/pathtracer.cu:164-174
 //  sphere (64 B, 4 x float4): center rad | material (12 f)
 #pragma once
@@ -34,11 +45,10 @@ constexpr int kBlockThreads = 64 * kWavesPerBlock;
 
 struct DevScene {
     const float4* nodes;      // traversal tree (SAH over triangles), 4 x float4 per record
+    const uint4* quad;        // its 4-wide quantised collapse, 4 x uint4 per record (wf_trace)
     const float4* tri;        // triangle test records in TREE order: (V0,prim) (E1,refLeaf) (E2,0)
-    const float4* tri_ref;    // (V0,0)(E1,0)(E2,0) in the REFERENCE's order (indexed by primitive), for shading
     const float4* leafbox;    // the reference's leaf boxes: 2 x float4 per reference leaf
-    const float4* shade;
-    const float4* mats;
+    const float4* surf;       // surface records, 12 x float4 per primitive (reference order)
     const float4* lights;
     const float4* spheres;
     int32_t n_nodes, n_tris, n_lights, n_spheres;

@@ -15,9 +15,8 @@ struct Surf {
     Mat m;
 };
 
-PT_DEV Mat load_mat(const float4* __restrict__ mats, int idx)
+PT_DEV Mat mat_from(const float4 a, const float4 b, const float4 c)
 {
-    const float4 a = mats[3 * idx], b = mats[3 * idx + 1], c = mats[3 * idx + 2];
     Mat m;
     m.emittance = f3(a.x, a.y, a.z);
     m.albedo = f3(a.w, b.x, b.y);
@@ -25,60 +24,76 @@ PT_DEV Mat load_mat(const float4* __restrict__ mats, int idx)
     m.opacity = c.y; m.roughness = c.z; m.metallic = c.w;
     return m;
 }
-PT_DEV Mat sphere_mat(const float4* __restrict__ sph, int s) { return load_mat(sph + 4 * s + 1, 0); }
+PT_DEV Mat sphere_mat(const float4* __restrict__ sph, int s) { return mat_from(sph[4 * s + 1], sph[4 * s + 2], sph[4 * s + 3]); }
 
-PT_DEV int tri_mat_index(const DevScene& sc, int prim) { return __float_as_int(sc.shade[7 * prim + 6].w); }
+// One triangle's surface record (pt_device.h): 12 independent 16-byte loads, no index chasing.
+struct SurfRec { float4 q[12]; };
+PT_DEV void load_surf(const DevScene& sc, int prim, SurfRec& r)      // 0 <= prim < n_tris
+{
+    const float4* __restrict__ p = sc.surf + 12 * (size_t)prim;
+#pragma unroll
+    for (int k = 0; k < 12; k++) r.q[k] = p[k];
+}
+// emittance of a triangle (first material quad of its record: emittance.xyz | albedo.x)
+PT_DEV float4 tri_emit4(const DevScene& sc, int prim) { return sc.surf[12 * (size_t)prim + 9]; }
 
 // emittance of whatever primitive `prim` is (GetLightColor returns hitResult.mat.emittance)
 PT_DEV f3 prim_emittance(const DevScene& sc, int prim)
 {
-    if (prim < sc.n_tris) {
-        const float4 a = sc.mats[3 * tri_mat_index(sc, prim)];
-        return f3(a.x, a.y, a.z);
-    }
-    const float4 a = sc.spheres[4 * (prim - sc.n_tris) + 1];
+    const float4 a = (prim < sc.n_tris) ? tri_emit4(sc, prim) : sc.spheres[4 * (prim - sc.n_tris) + 1];
     return f3(a.x, a.y, a.z);
 }
 
-// Rebuild the reference's HitResult for the closest hit (Triangle::hit tail,
-// CudaPrimitive.cuh:117-156; Sphere::hit tail, :274-301).  u,v are recomputed with the
-// same operations the traversal used, so they carry the same bits.
+// Rebuild the reference's HitResult for a closest hit on a triangle (Triangle::hit tail,
+// CudaPrimitive.cuh:117-156) from its surface record.  u,v are recomputed with the same
+// operations the traversal used, so they carry the same bits.
+PT_DEV void surf_from_rec(const SurfRec& r, float t, const f3& org, const f3& dir, Surf& s)
+{
+    const float4* q = r.q;
+    s.p = org + t * dir;                                              // Ray::at
+    const f3 V0(q[0].x, q[0].y, q[0].z), E1(q[0].w, q[1].x, q[1].y), E2(q[1].z, q[1].w, q[2].x);
+    const f3 T = org - V0;
+    const f3 P = cross(dir, E2);
+    const f3 Q = cross(T, E1);
+    const float det = dot(P, E1);
+    const float invDet = 1.f / det;
+    float u = dot(P, T);
+    float v = dot(Q, dir);
+    u *= invDet;
+    v *= invDet;
+    const float w = 1.f - v - u;
+    const f3 N0(q[2].y, q[2].z, q[2].w), N1(q[3].x, q[3].y, q[3].z), N2(q[3].w, q[4].x, q[4].y);
+    const f3 T0(q[4].z, q[4].w, q[5].x), T1(q[5].y, q[5].z, q[5].w), T2(q[6].x, q[6].y, q[6].z);
+    const f3 B0(q[6].w, q[7].x, q[7].y), B1(q[7].z, q[7].w, q[8].x), B2(q[8].y, q[8].z, q[8].w);
+    const f3 outward = normalize(w * N0 + v * N1 + u * N2);          // weights swapped on purpose (Q5)
+    s.fr.front = dot(dir, outward) < 0.f;                             // HitResult::SetNormal
+    s.fr.n = s.fr.front ? outward : -outward;
+    s.fr.t = normalize(w * T0 + v * T1 + u * T2);
+    s.fr.b = normalize(w * B0 + v * B1 + u * B2);
+    s.m = mat_from(q[9], q[10], q[11]);
+}
+
+// Sphere::hit tail (CudaPrimitive.cuh:274-301)
+PT_DEV void surf_sphere(const DevScene& sc, int si, float t, const f3& org, const f3& dir, Surf& s)
+{
+    s.p = org + t * dir;
+    const float4 c = sc.spheres[4 * si];
+    const f3 outward = (s.p - f3(c.x, c.y, c.z)) / c.w;
+    s.fr.front = dot(dir, outward) < 0.f;
+    s.fr.n = s.fr.front ? outward : -outward;
+    s.fr.t = normalize(cross(f3(0.f, 1.f, 0.f), s.fr.n));
+    s.fr.b = cross(s.fr.n, s.fr.t);
+    s.m = sphere_mat(sc.spheres, si);
+}
+
 PT_DEV void make_surf(const DevScene& sc, int prim, float t, const f3& org, const f3& dir, Surf& s)
 {
-    s.p = org + t * dir;                                              // Ray::at
     if (prim < sc.n_tris) {
-        const float4 a = sc.tri_ref[3 * prim], b = sc.tri_ref[3 * prim + 1], c = sc.tri_ref[3 * prim + 2];
-        const f3 V0(a.x, a.y, a.z), E1(b.x, b.y, b.z), E2(c.x, c.y, c.z);
-        const f3 T = org - V0;
-        const f3 P = cross(dir, E2);
-        const f3 Q = cross(T, E1);
-        const float det = dot(P, E1);
-        const float invDet = 1.f / det;
-        float u = dot(P, T);
-        float v = dot(Q, dir);
-        u *= invDet;
-        v *= invDet;
-        const float w = 1.f - v - u;
-        const float4* sh = sc.shade + 7 * prim;
-        const float4 s0 = sh[0], s1 = sh[1], s2 = sh[2], s3 = sh[3], s4 = sh[4], s5 = sh[5], s6 = sh[6];
-        const f3 N0(s0.x, s0.y, s0.z), N1(s0.w, s1.x, s1.y), N2(s1.z, s1.w, s2.x);
-        const f3 T0(s2.y, s2.z, s2.w), T1(s3.x, s3.y, s3.z), T2(s3.w, s4.x, s4.y);
-        const f3 B0(s4.z, s4.w, s5.x), B1(s5.y, s5.z, s5.w), B2(s6.x, s6.y, s6.z);
-        const f3 outward = normalize(w * N0 + v * N1 + u * N2);      // weights swapped on purpose (Q5)
-        s.fr.front = dot(dir, outward) < 0.f;                         // HitResult::SetNormal
-        s.fr.n = s.fr.front ? outward : -outward;
-        s.fr.t = normalize(w * T0 + v * T1 + u * T2);
-        s.fr.b = normalize(w * B0 + v * B1 + u * B2);
-        s.m = load_mat(sc.mats, __float_as_int(s6.w));
+        SurfRec r;
+        load_surf(sc, prim, r);
+        surf_from_rec(r, t, org, dir, s);
     } else {
-        const int si = prim - sc.n_tris;
-        const float4 c = sc.spheres[4 * si];
-        const f3 outward = (s.p - f3(c.x, c.y, c.z)) / c.w;
-        s.fr.front = dot(dir, outward) < 0.f;
-        s.fr.n = s.fr.front ? outward : -outward;
-        s.fr.t = normalize(cross(f3(0.f, 1.f, 0.f), s.fr.n));
-        s.fr.b = cross(s.fr.n, s.fr.t);
-        s.m = sphere_mat(sc.spheres, si);
+        surf_sphere(sc, prim - sc.n_tris, t, org, dir, s);
     }
 }
 

@@ -103,20 +103,34 @@ PT_DEV bool shade_step(const DevScene& sc, const DevCamera& cam, const DevParams
     const uint32_t flags = st.flags;
     bool bRefracted = (flags & F_REFR) != 0;
     const int Nl = sc.n_lights;
+    // ---- 0. the scene fetches of the bounce, issued together ----
+    // The path hit's surface record (one 192-B record: no index chasing), the shadow hit's emittance and
+    // the light the NEE draw will pick (its random word is peeked) are requested up front with clamped
+    // indices instead of branches, so the compiler can keep them all in flight.  The two per-pixel
+    // values a retiring path needs stay lazy: ~40 % of the steps use them, and the kernel is limited by
+    // memory throughput (its time does not change between 2, 3 and 4 waves/SIMD), not by fetch depth.
+    const int primP = (flags & F_PATH) ? __float_as_int(hitP.y) : -1;
+    const int primS = (flags & F_SHADOW) ? __float_as_int(hitS.y) : -1;
+    const bool triP = primP >= 0 && primP < sc.n_tris;
+    SurfRec rec;
+    load_surf(sc, triP ? primP : 0, rec);
+    const float4 emS = tri_emit4(sc, (primS >= 0 && primS < sc.n_tris) ? primS : 0);
+    Rng peek = st.rng;
+    const int li = (int)(peek.next() % (uint32_t)Nl);
+    const float4 l0 = sc.lights[4 * li], l1 = sc.lights[4 * li + 1], l2 = sc.lights[4 * li + 2], l3 = sc.lights[4 * li + 3];
     // ---- 1. pending NEE term (GetLightColor tail + CudaUtil.cuh:271-272) ----
     if (flags & F_SHADOW) {
-        const int sprim = __float_as_int(hitS.y);
         f3 Le(0.f, 0.f, 0.f);
-        if (sprim >= 0) {
+        if (primS >= 0) {
             const f3 hp = st.shO + hitS.x * st.shD;
-            if (length(hp - st.lightP) < kEps) Le = prim_emittance(sc, sprim);
+            if (length(hp - st.lightP) < kEps) Le = (primS < sc.n_tris) ? f3(emS.x, emS.y, emS.z) : prim_emittance(sc, primS);
         }
         if (flags & F_NEEOK) st.radiance += ((st.wb * Le) * st.cosA) / st.denom;
     }
     // ---- 2. the traced path ray belongs to the next sample: retire the old path first ----
     bool streamDone = false;
     auto retire = [&]() {                                        // pathtracer.cu:79
-        if (!st.pixLoaded) { const float4 pq = *pixPtr; st.pixelColor = f3(pq.x, pq.y, pq.z); st.pixLoaded = true; }
+        if (!st.pixLoaded) { const float4 pix0 = *pixPtr; st.pixelColor = f3(pix0.x, pix0.y, pix0.z); st.pixLoaded = true; }
         st.pixelColor += st.radiance;
         st.samplesLeft--;
         st.weight = f3(1.f, 1.f, 1.f); st.radiance = f3(0.f, 0.f, 0.f);
@@ -126,23 +140,22 @@ PT_DEV bool shade_step(const DevScene& sc, const DevCamera& cam, const DevParams
 
     uint32_t nflags = 0;
     if (flags & F_PATH) {
-        const int prim = __float_as_int(hitP.y);
         const f3 rorg = st.pathO, rdir = st.pathD;
-        if (prim < 0) {
+        if (primP < 0) {
             st.radiance += st.weight * f3(0.1f, 0.1f, 0.1f);               // CudaUtil.cuh:375-379
             retire();
             if (st.samplesLeft > 0) nflags = F_PATH; else streamDone = true;
         } else {
             // ---- shade a PATH hit: the whole bounce except visibility ----
             Surf s;
-            make_surf(sc, prim, hitP.x, rorg, rdir, s);
+            if (triP) surf_from_rec(rec, hitP.x, rorg, rdir, s);
+            else surf_sphere(sc, primP - sc.n_tris, hitP.x, rorg, rdir, s);
             if (sqlen(s.m.emittance) > kEps) st.radiance += st.weight * s.m.emittance;   // :220-224
             const float ior = ior_of(s.m);                                          // :231
             const int lobe = lobe_of(s.m);
             const f3 wo = -rdir;
             // NEE sample (:235-245, SamplePrimitive :38-48)
-            const int li = (int)(st.rng.next() % (uint32_t)Nl);
-            const float4 l0 = sc.lights[4 * li], l1 = sc.lights[4 * li + 1], l2 = sc.lights[4 * li + 2], l3 = sc.lights[4 * li + 3];
+            st.rng = peek;                                  // the light index drawn above: first draw of the bounce
             const f3 LV0(l0.x, l0.y, l0.z), LV1(l0.w, l1.x, l1.y), LV2(l1.z, l1.w, l2.x), LN(l2.y, l2.z, l2.w);
             const float r1u = __builtin_sqrtf(st.rng.uniform());
             const float r2u = st.rng.uniform();
@@ -197,9 +210,9 @@ PT_DEV bool shade_step(const DevScene& sc, const DevCamera& cam, const DevParams
         streamDone = true;
     }
     if (((nflags & F_PATH) && !(nflags & F_SHADOW)) || (nflags & F_NEWPATH)) {
-        const float4 d0 = *dir0Ptr;
+        const float4 cam0 = *dir0Ptr;
         st.pathO = f3(cam.pos[0], cam.pos[1], cam.pos[2]);
-        st.pathD = f3(d0.x, d0.y, d0.z);
+        st.pathD = f3(cam0.x, cam0.y, cam0.z);
     }
     if (bRefracted) nflags |= F_REFR;
     st.flags = nflags;
@@ -218,15 +231,13 @@ PT_DEV void load_state(const WfBuf& b, uint32_t sid, SState& st)
     st.pixelColor = f3(0.f, 0.f, 0.f); st.pixLoaded = false;
     st.wb = f3(0.f, 0.f, 0.f); st.lightP = f3(0.f, 0.f, 0.f);
     st.pathO = st.pathD = st.shO = st.shD = f3(0.f, 0.f, 0.f); st.shTmax = 0.f;
-    if (st.flags & F_PATH) {
-        const float4 po = b.ray_o[0][sid], pd = b.ray_d[0][sid];
-        st.pathO = f3(po.x, po.y, po.z); st.pathD = f3(pd.x, pd.y, pd.z);
-    }
-    if (st.flags & F_SHADOW) {
-        const float4 so = b.ray_o[1][sid], sd = b.ray_d[1][sid], lpq = b.lp[sid], wbq = b.wb[sid];
-        st.shO = f3(so.x, so.y, so.z); st.shD = f3(sd.x, sd.y, sd.z); st.shTmax = so.w;
-        st.lightP = f3(lpq.x, lpq.y, lpq.z); st.wb = f3(wbq.x, wbq.y, wbq.z);
-    }
+    // rays and the pending NEE term are fetched whatever the flags say (stale values are never used):
+    // waiting for the flags first would add a level to the kernel's dependent-load chain
+    const float4 po = b.ray_o[0][sid], pd = b.ray_d[0][sid];
+    st.pathO = f3(po.x, po.y, po.z); st.pathD = f3(pd.x, pd.y, pd.z);
+    const float4 so = b.ray_o[1][sid], sd = b.ray_d[1][sid], lpq = b.lp[sid], wbq = b.wb[sid];
+    st.shO = f3(so.x, so.y, so.z); st.shD = f3(sd.x, sd.y, sd.z); st.shTmax = so.w;
+    st.lightP = f3(lpq.x, lpq.y, lpq.z); st.wb = f3(wbq.x, wbq.y, wbq.z);
 }
 
 PT_DEV void write_mean(const WfBuf& b, const DevParams& prm, uint32_t sid, const SState& st)

@@ -142,8 +142,8 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
     bool hasRay = false;
     // per-ray registers
     uint32_t sid = 0;
-    f3 org(0.f, 0.f, 0.f), dir(0.f, 0.f, 1.f), invD(0.f, 0.f, 0.f);
-    float bestT = 0.f, cullB = 0.f, kcull = 0.f, stopBelow = 0.f;
+    f3 org(0.f, 0.f, 0.f), dir(0.f, 0.f, 1.f), inv(0.f, 0.f, 0.f);   // inv: 1/dir, clamped to +-1e30 (see the node step)
+    float bestT = 0.f, invLen = 0.f, stopBelow = 0.f;
     int bestPrim = -1, cur = kDone, sp = 0, steps = 0;
     bool degenerate = false, shadow = false;
     float2* hitOut = b.hit[0];
@@ -185,11 +185,13 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                         hitOut = shadow ? b.hit[1] : b.hit[0];
                         const float4 o = (shadow ? b.ray_o[1] : b.ray_o[0])[sid], d = (shadow ? b.ray_d[1] : b.ray_d[0])[sid];
                         org = f3(o.x, o.y, o.z); dir = f3(d.x, d.y, d.z);
-                        const f3 inv(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);                 // inv(), CudaUtil.cuh:60-63
-                        const float L = __builtin_sqrtf(inv.x * inv.x + inv.y * inv.y + inv.z * inv.z);
-                        invD = inv / L;                                                      // Normalize(inv(dir)), :70
-                        degenerate = !(L < __builtin_inff());
-                        kcull = degenerate ? 1.0078125f : 1.0078125f / L;
+                        inv = f3(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);                     // inv(), CudaUtil.cuh:60-63
+                        invLen = __builtin_sqrtf(inv.x * inv.x + inv.y * inv.y + inv.z * inv.z);   // |inv(dir)| of Normalize(inv(dir)), :70
+                        degenerate = !(invLen < __builtin_inff());
+                        // the tree walk wants a finite inverse direction (a non-degenerate ray's is untouched: |inv| < 1.9e19)
+                        inv.x = (__builtin_fabsf(inv.x) <= 1e30f) ? inv.x : __builtin_copysignf(1e30f, dir.x);
+                        inv.y = (__builtin_fabsf(inv.y) <= 1e30f) ? inv.y : __builtin_copysignf(1e30f, dir.y);
+                        inv.z = (__builtin_fabsf(inv.z) <= 1e30f) ? inv.z : __builtin_copysignf(1e30f, dir.z);
                         stopBelow = shadow ? (o.w - 1.0f) - 5e-4f : -__builtin_inff();
                         steps = 0;
                         const float2 prev = hitOut[sid];
@@ -205,7 +207,6 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                         } else {
                             bestT = o.w; bestPrim = -1; cur = 0; sp = 0;
                         }
-                        cullB = bestT * kcull;
                         hasRay = true;
                     }
                 }
@@ -243,31 +244,59 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
             const bool doTri = !doNode;
             if (doNode && cur >= 0) {
                 steps++;
-                const float4 q0 = sc.nodes[4 * cur + 0];
-                const float4 q1 = sc.nodes[4 * cur + 1];
-                const float4 q2 = sc.nodes[4 * cur + 2];
-                const float4 q3 = sc.nodes[4 * cur + 3];
-                float tnL, tnR;
-                bool okL, okR;
-                if (!degenerate) {
-                    okL = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, org, invD, cullB, tnL);
-                    okR = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, org, invD, cullB, tnR);
-                } else {
-                    const f3 inv(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);
-                    okL = box_test_robust(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, org, dir, inv, cullB, tnL);
-                    okR = box_test_robust(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, org, dir, inv, cullB, tnR);
+                // ---- one 4-wide node: conservative slab test of its four quantised child boxes ----
+                // Child box = origin + 2^e * q.  Along each axis t(q) = q*A + B with A = 2^e / dir and
+                // B = (origin - org) / dir; both are widened by `sl` (2^-20 of their magnitudes, ~16 ulps),
+                // the near/far bytes are picked by the sign of the direction once per node (all four children
+                // of a coordinate share a dword), and the far side is cut at the closest hit.  The boxes only
+                // steer the search — acceptance is Triangle::hit + the reference's leaf box — so all that
+                // matters is that no box containing a point the ray reaches is ever rejected.
+                const uint4* np = sc.quad + 4 * (size_t)cur;
+                const uint4 n0 = np[0], n1 = np[1], n2 = np[2];
+                const uint2 n3 = *(const uint2*)(np + 3);
+                const int eb = (int)n0.w;
+                const float Ax = __builtin_ldexpf(inv.x, (int)(signed char)(eb & 0xff));
+                const float Ay = __builtin_ldexpf(inv.y, (int)(signed char)((eb >> 8) & 0xff));
+                const float Az = __builtin_ldexpf(inv.z, (int)(signed char)((eb >> 16) & 0xff));
+                const float Bx = (__uint_as_float(n0.x) - org.x) * inv.x;
+                const float By = (__uint_as_float(n0.y) - org.y) * inv.y;
+                const float Bz = (__uint_as_float(n0.z) - org.z) * inv.z;
+                const float kSl = 9.5367431640625e-7f;                           // 2^-20
+                const float sx = (__builtin_fabsf(Bx) + 255.f * __builtin_fabsf(Ax)) * kSl;
+                const float sy = (__builtin_fabsf(By) + 255.f * __builtin_fabsf(Ay)) * kSl;
+                const float sz = (__builtin_fabsf(Bz) + 255.f * __builtin_fabsf(Az)) * kSl;
+                const float Bnx = Bx - sx, Bfx = Bx + sx, Bny = By - sy, Bfy = By + sy, Bnz = Bz - sz, Bfz = Bz + sz;
+                const bool px = inv.x >= 0.f, py = inv.y >= 0.f, pz = inv.z >= 0.f;
+                const uint32_t nqx = px ? n2.x : n2.w, fqx = px ? n2.w : n2.x;   // lo.x = n2.x, hi.x = n2.w
+                const uint32_t nqy = py ? n2.y : n3.x, fqy = py ? n3.x : n2.y;   // lo.y = n2.y, hi.y = n3.x
+                const uint32_t nqz = pz ? n2.z : n3.y, fqz = pz ? n3.y : n2.z;   // lo.z = n2.z, hi.z = n3.y
+                const float cullT = bestT * 1.00000095f;
+                int key[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float tnx = __builtin_fmaf((float)((nqx >> (8 * k)) & 0xffu), Ax, Bnx);
+                    const float tny = __builtin_fmaf((float)((nqy >> (8 * k)) & 0xffu), Ay, Bny);
+                    const float tnz = __builtin_fmaf((float)((nqz >> (8 * k)) & 0xffu), Az, Bnz);
+                    const float tfx = __builtin_fmaf((float)((fqx >> (8 * k)) & 0xffu), Ax, Bfx);
+                    const float tfy = __builtin_fmaf((float)((fqy >> (8 * k)) & 0xffu), Ay, Bfy);
+                    const float tfz = __builtin_fmaf((float)((fqz >> (8 * k)) & 0xffu), Az, Bfz);
+                    const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.f));
+                    const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, cullT));
+                    key[k] = (tn <= tf) ? ((__float_as_int(tn) & ~3) | k) : 0x7fffffff;   // tn >= 0: its bits order like ints
                 }
-                const int refL = __float_as_int(q3.x), refR = __float_as_int(q3.y);
-                if (okL & okR) {
-                    const bool lNear = tnL <= tnR;
-                    const int farRef = lNear ? refR : refL;
-                    if (sp < kWfLdsStack) stack[sp * 64] = farRef; else ovf[(sp - kWfLdsStack) * ovfStride] = farRef;
-                    sp++;
-                    cur = lNear ? refL : refR;
-                } else if (okL) {
-                    cur = refL;
-                } else if (okR) {
-                    cur = refR;
+                const int refs[4] = {(int)n1.x, (int)n1.y, (int)n1.z, (int)n1.w};
+                const int kmin = min(min(key[0], key[1]), min(key[2], key[3]));
+                if (kmin != 0x7fffffff) {
+                    // nearest child next; the other hit children go to the stack
+                    const int idxN = kmin & 3;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (key[k] != 0x7fffffff && k != idxN) {
+                            if (sp < kWfLdsStack) stack[sp * 64] = refs[k]; else ovf[(sp - kWfLdsStack) * ovfStride] = refs[k];
+                            sp++;
+                        }
+                    }
+                    cur = idxN == 0 ? refs[0] : (idxN == 1 ? refs[1] : (idxN == 2 ? refs[2] : refs[3]));
                 } else if (sp == 0) {
                     cur = kDone;
                 } else {
@@ -279,8 +308,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 const int code = ~cur, first = code >> 3, cnt = code & 7;
                 bool pop = true;
                 if (cnt > 0) {
-                    tri_test(sc, first, org, dir, invD, degenerate, bestT, bestPrim);
-                    cullB = bestT * kcull;
+                    tri_test_lazy(sc, first, org, dir, inv, invLen, degenerate, bestT, bestPrim);
                     if (bestPrim >= 0 && bestT < stopBelow) { cur = kDone; pop = false; }
                     else if (cnt > 1) { cur = ~(((first + 1) << 3) | (cnt - 1)); pop = false; }
                 }
@@ -310,20 +338,19 @@ __global__ __launch_bounds__(kShadeThreads, 4)
 void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, int slotOut, int slotClear, int listIn)
 {
     const uint32_t nIn = b.cnt[slotIn].nActive;
-    if (blockIdx.x == 0) for (int k = threadIdx.x; k < kWfSlotBytes / 4; k += kShadeThreads) ((uint32_t*)&b.cnt[slotClear])[k] = 0;
-    if ((uint32_t)blockIdx.x * (uint32_t)kShadeThreads >= nIn) return;
-    const uint32_t idx = blockIdx.x * (uint32_t)kShadeThreads + threadIdx.x;
+    if (blockIdx.x == 0) for (int k = threadIdx.x; k < kWfSlotBytes / 4; k += blockDim.x) ((uint32_t*)&b.cnt[slotClear])[k] = 0;
+    if ((uint32_t)blockIdx.x * blockDim.x >= nIn) return;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const bool have = idx < nIn;
     bool emitPath = false, emitShadow = false, alive = false;
     uint32_t sid = 0;
     if (have) {
         sid = b.active[listIn][idx];
         SState st;
+        const float2 hitP = b.hit[0][sid], hitS = b.hit[1][sid];      // same fetch level as the state
         load_state(b, sid, st);
         // a ray of this stream is still being traversed (time-sliced): wait one iteration
-        const float2 hitP = (st.flags & F_PATH) ? b.hit[0][sid] : make_float2(0.f, __int_as_float(-1));
-        const float2 hitS = (st.flags & F_SHADOW) ? b.hit[1][sid] : make_float2(0.f, __int_as_float(-1));
-        const int pendP = __float_as_int(hitP.y), pendS = __float_as_int(hitS.y);
+        const int pendP = (st.flags & F_PATH) ? __float_as_int(hitP.y) : -1, pendS = (st.flags & F_SHADOW) ? __float_as_int(hitS.y) : -1;
         if (pendP <= -2 || pendS <= -2) {
             alive = true; emitPath = pendP <= -2; emitShadow = pendS <= -2;
         } else {
@@ -463,9 +490,13 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     static const int guideShift = getenv("PTAMD_GS") ? atoi(getenv("PTAMD_GS")) : 9;
     static const int budgetShift = getenv("PTAMD_BS") ? atoi(getenv("PTAMD_BS")) : 14;
     static const int budgetMin = getenv("PTAMD_BM") ? atoi(getenv("PTAMD_BM")) : kWfBudget;
+    static const int shadeThreads = getenv("PTAMD_ST") ? atoi(getenv("PTAMD_ST")) : kShadeThreads;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
     int it = 0;
     int poll = 16;
+    // streams only ever retire, so the live count of the last poll bounds every later one: the shade grid
+    // shrinks with it instead of launching thousands of workgroups that find nothing to do
+    uint32_t liveBound = (uint32_t)nStreams;
     for (;;) {
         for (int k = 0; k < poll; k++, it++) {
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
@@ -473,12 +504,13 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
             hipLaunchKernelGGL(wf_trace, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
-            hipLaunchKernelGGL(wf_shade, dim3((nb * 256 + kShadeThreads - 1) / kShadeThreads), dim3(kShadeThreads), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
+            hipLaunchKernelGGL(wf_shade, dim3((liveBound + shadeThreads - 1) / shadeThreads), dim3(shadeThreads), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(h_cnt, &b.cnt[it % 3].nActive, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
         if (h_cnt[0] == 0) break;
+        liveBound = h_cnt[0];
         if (h_cnt[0] <= (uint32_t)drainBelow) {
             // few streams left: finish them in one launch instead of hundreds of latency-bound iterations
             const int db = (int)((h_cnt[0] + kBlockThreads - 1) / kBlockThreads);

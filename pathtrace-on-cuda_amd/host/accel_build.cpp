@@ -18,6 +18,13 @@
 //     only counts if the box passes — which reproduces the reference's acceptance exactly.
 //
 // 16.2 node records + 4.1 triangle tests per ray on the same rays (tools/trav_lab2.cpp).
+//
+// The queue-driven traversal kernel (csrc/pt_wavefront.hip) walks a 4-WIDE collapse of that tree:
+// a ray's traversal is a chain of dependent fetches, and halving the depth of the tree shortens
+// the chain.  A 4-wide node is still one 64-byte record because its child boxes are quantised to
+// 8 bits per coordinate against the node's own origin and power-of-two scale (rounded outward, on
+// top of the padding above).  That is safe for the same reason the padding is: the boxes only
+// steer the search; acceptance is decided by Triangle::hit and the reference's leaf box.
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -213,4 +220,114 @@ void pt_build_accel(const PtBVHNode* rnodes, int n_rnodes, const PtTriangle* tri
     }
     out.n_wide = n_wide;
     out.n_leaves = n_leaves;
+
+    // ---- 4-wide quantised collapse ----
+    // absolute pad on top of the relative one: Moeller-Trumbore's own rounding is relative to the ray's
+    // coordinates, not to a box face that happens to lie near a coordinate plane
+    float maxAbs = 0.f;
+    for (const BN& n : b.nodes) for (int a = 0; a < 3; a++) maxAbs = std::max(maxAbs, std::max(std::fabs(n.mn[a]), std::fabs(n.mx[a])));
+    const float absPad = maxAbs * 9.5367431640625e-7f;      // 2^-20
+    struct Q4 { uint32_t d[16]; };
+    std::vector<Q4> quad;
+    int quadDepth = 0;
+    struct Emit {
+        Builder& b; std::vector<Q4>& quad; float absPad; int& maxDepth;
+        int run(int bnode, int depth)
+        {
+            if (depth > maxDepth) maxDepth = depth;
+            int ch[4]; int nc = 0;
+            ch[nc++] = b.nodes[(size_t)bnode].l; ch[nc++] = b.nodes[(size_t)bnode].r;
+            while (nc < 4) {
+                int pick = -1; float pa = -1.f;
+                for (int k = 0; k < nc; k++) {
+                    const BN& c = b.nodes[(size_t)ch[k]];
+                    if (c.count > 0) continue;
+                    const float ar = Builder::area(c.mn, c.mx);
+                    if (ar > pa) { pa = ar; pick = k; }
+                }
+                if (pick < 0) break;
+                const BN& c = b.nodes[(size_t)ch[pick]];
+                const int l = c.l, r = c.r;
+                ch[pick] = l; ch[nc++] = r;
+            }
+            const int me = (int)quad.size();
+            quad.emplace_back();
+            float lo[4][3], hi[4][3];
+            for (int k = 0; k < nc; k++) {
+                const BN& c = b.nodes[(size_t)ch[k]];
+                for (int a = 0; a < 3; a++) { lo[k][a] = pad_lo(c.mn[a]) - absPad; hi[k][a] = pad_hi(c.mx[a]) + absPad; }
+            }
+            float org[3]; int e[3];
+            uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+            for (int a = 0; a < 3; a++) {
+                float mn = lo[0][a], mx = hi[0][a];
+                for (int k = 1; k < nc; k++) { mn = std::min(mn, lo[k][a]); mx = std::max(mx, hi[k][a]); }
+                org[a] = mn;
+                int ex = -100;
+                if (mx > mn) { int t; std::frexp((mx - mn) / 255.f, &t); ex = std::max(t - 1, -100); }
+                for (;;) {
+                    const float sc = std::ldexp(1.f, ex);
+                    bool ok = true;
+                    uint32_t wl = 0, wh = 0;
+                    for (int k = 0; k < 4 && ok; k++) {
+                        int ql, qh;
+                        if (k < nc) {
+                            ql = (int)std::floor((lo[k][a] - mn) / sc);
+                            if (ql < 0) ql = 0;
+                            while (ql > 0 && mn + sc * (float)ql > lo[k][a]) ql--;
+                            qh = (int)std::ceil((hi[k][a] - mn) / sc);
+                            if (qh < ql) qh = ql;
+                            while (qh <= 255 && mn + sc * (float)qh < hi[k][a]) qh++;
+                            if (qh > 255 || ql > 255) { ok = false; break; }
+                        } else { ql = 255; qh = 0; }          // no child: an inverted box
+                        wl |= (uint32_t)ql << (8 * k); wh |= (uint32_t)qh << (8 * k);
+                    }
+                    if (ok) { qlo[a] = wl; qhi[a] = wh; e[a] = ex; break; }
+                    ex++;
+                }
+            }
+            uint32_t refs[4];
+            for (int k = 0; k < 4; k++) {
+                if (k >= nc) { refs[k] = (uint32_t)~0; continue; }
+                const BN& c = b.nodes[(size_t)ch[k]];
+                if (c.count > 0) refs[k] = (uint32_t)~((c.first << 3) | c.count);
+                else refs[k] = (uint32_t)run(ch[k], depth + 1);
+            }
+            Q4& q = quad[(size_t)me];
+            memcpy(&q.d[0], org, 12);
+            q.d[3] = ((uint32_t)(uint8_t)(int8_t)e[0]) | ((uint32_t)(uint8_t)(int8_t)e[1] << 8) | ((uint32_t)(uint8_t)(int8_t)e[2] << 16);
+            for (int k = 0; k < 4; k++) q.d[4 + k] = refs[k];
+            q.d[8] = qlo[0]; q.d[9] = qlo[1]; q.d[10] = qlo[2];
+            q.d[11] = qhi[0]; q.d[12] = qhi[1]; q.d[13] = qhi[2];
+            q.d[14] = 0; q.d[15] = 0;
+            return me;
+        }
+    };
+    if (b.nodes[0].count > 0) {
+        // a single leaf: one node whose first child is that leaf
+        quad.emplace_back();
+        Q4& q = quad[0];
+        memset(&q, 0, sizeof(q));
+        float org[3]; uint32_t qh[3];
+        int e[3];
+        for (int a = 0; a < 3; a++) {
+            const float mn = pad_lo(b.nodes[0].mn[a]) - absPad, mx = pad_hi(b.nodes[0].mx[a]) + absPad;
+            org[a] = mn;
+            int ex = -100;
+            if (mx > mn) { int t; std::frexp((mx - mn) / 255.f, &t); ex = std::max(t - 1, -100); }
+            for (;;) { const float sc = std::ldexp(1.f, ex); int q1 = (int)std::ceil((mx - mn) / sc); while (q1 <= 255 && mn + sc * (float)q1 < mx) q1++; if (q1 <= 255) { qh[a] = (uint32_t)q1; e[a] = ex; break; } ex++; }
+        }
+        memcpy(&q.d[0], org, 12);
+        q.d[3] = ((uint32_t)(uint8_t)(int8_t)e[0]) | ((uint32_t)(uint8_t)(int8_t)e[1] << 8) | ((uint32_t)(uint8_t)(int8_t)e[2] << 16);
+        q.d[4] = (uint32_t)~((b.nodes[0].first << 3) | b.nodes[0].count);
+        q.d[5] = q.d[6] = q.d[7] = (uint32_t)~0;
+        for (int a = 0; a < 3; a++) { q.d[8 + a] = 0u | (255u << 8) | (255u << 16) | (255u << 24); q.d[11 + a] = qh[a]; }
+    } else {
+        Emit em{b, quad, absPad, quadDepth};
+        em.run(0, 0);
+    }
+    out.quad.resize(quad.size() * 16);
+    memcpy(out.quad.data(), quad.data(), quad.size() * sizeof(Q4));
+    out.n_quad = (int)quad.size();
+    out.quad_depth = quadDepth;
 }

@@ -1,5 +1,6 @@
 // accel_build.h — device acceleration structure built at upload (see accel_build.cpp).
 #pragma once
+#include <cstdint>
 #include <vector>
 #include "../../include/pt_api.h"
 
@@ -9,7 +10,9 @@ struct PtAccel {
     std::vector<float> wide;             // n_wide x 16 floats (two child boxes + two refs)
     std::vector<float> tri;              // n_tris x 12 floats, tree order: (V0,prim) (E1,refLeaf) (E2,0)
     std::vector<float> leafbox;          // n_leaves x 8 floats: the reference's leaf boxes, verbatim
+    std::vector<uint32_t> quad;          // n_quad x 16 dwords: the 4-wide quantised tree (layout: csrc/pt_device.h)
     int n_wide = 0, n_leaves = 0, depth = 0;
+    int n_quad = 0, quad_depth = 0;
 };
 
 void pt_build_accel(const PtBVHNode* ref_nodes, int n_ref_nodes, const PtTriangle* tris, int n_tris, PtAccel& out);
