@@ -32,6 +32,7 @@ hipError_t ptk_pw_render(const ptd::DevScene*, const ptd::DevCamera*, const ptd:
 size_t ptk_wf_work_bytes(size_t nUnits, int traceBlocks);
 int ptk_wf_cohorts(size_t nUnits);
 const float* ptk_wf_staging(void* work);
+void ptk_wf_set_stat(void*);
 hipError_t ptk_wf_render(int, const ptd::DevScene*, const ptd::DevCamera*, const ptd::DevParams*, void*, int, uint32_t*, hipStream_t, hipStream_t*,
                          hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t*, int*, hipEvent_t*, int, int*, int);
 }
@@ -336,6 +337,10 @@ int pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm, float*
         const int C = ptk_wf_cohorts((size_t)d.n_units);
         s->trace_ev_per = s->trace_ev.empty() ? 0 : (int)(s->trace_ev.size() / 2) / C;
         for (int k = 0; k < 4; k++) s->trace_ev_used[k] = 0;
+        // diagnostic (PTAMD_TSTAT=1): wf_trace counts its trips and the lanes they serve; read with pt_last_counters
+        static const bool kTraceStat = getenv("PTAMD_TSTAT") && atoi(getenv("PTAMD_TSTAT")) != 0;
+        if (kTraceStat) HIPCHK(hipMemsetAsync(s->d_counters, 0, 64, stream));
+        ptk_wf_set_stat(kTraceStat ? s->d_counters : nullptr);
         HIPCHK(ptk_wf_render(s->device, &s->dev, &c, &d, d_work, kTraceBlocks, s->h_poll, stream, s->xstreams,
                              s->ev[slot][0], s->ev[slot][1], s->ev_fork, s->ev_join, &iters,
                              s->trace_ev.empty() ? nullptr : s->trace_ev.data(), (int)s->trace_ev.size() / 2, s->trace_ev_used, s->drain_below));

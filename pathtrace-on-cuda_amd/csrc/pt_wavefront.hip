@@ -114,9 +114,13 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
 // some occluder, for which wf_shade's |hit.p - P| < EPS test fails exactly as it would for the
 // closest one.
 // ---------------------------------------------------------------------------------------
+// STAT: a diagnostic build that also counts trips and the lanes they serve (pt_last_counters; PTAMD_TSTAT=1).
+template <bool STAT>
 __global__ __launch_bounds__(256, 8)
-void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift)
+void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift,
+              unsigned long long* stat)
 {
+    unsigned long long stNodeTrips = 0, stNodeLanes = 0, stTriTrips = 0, stTriLanes = 0, stRefills = 0, stRefillLanes = 0, stNoRayLanes = 0, stRays = 0;
     __shared__ int lds_stack[4][kWfLdsStack * 64];
     // one queue index space: [0, nPath) are path rays, [nPath, nPath + nShadow) shadow rays
     const uint32_t nPath = b.cnt[slot].nPath;
@@ -176,6 +180,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
             if (!exhausted) {
                 const uint32_t avail = chunkEnd - chunkPos;
                 const uint32_t take = ((uint32_t)nIdle < avail) ? (uint32_t)nIdle : avail;
+                if (STAT && take) { stRefills++; stRefillLanes += take; }
                 if (!hasRay) {
                     const uint32_t r = (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
                     if (r < take) {
@@ -242,6 +247,10 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
             const int nTri = __builtin_popcountll(__ballot(hasRay && cur < 0 && cur != kDone));
             const bool doNode = nNode >= nTri;
             const bool doTri = !doNode;
+            if (STAT) {
+                if (doNode) { stNodeTrips++; stNodeLanes += nNode; } else { stTriTrips++; stTriLanes += nTri; }
+                stNoRayLanes += 64 - __builtin_popcountll(__ballot(hasRay));
+            }
             if (doNode && cur >= 0) {
                 steps++;
                 // ---- one 4-wide node: conservative slab test of its four quantised child boxes ----
@@ -285,18 +294,16 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     key[k] = (tn <= tf) ? ((__float_as_int(tn) & ~3) | k) : 0x7fffffff;   // tn >= 0: its bits order like ints
                 }
                 const int refs[4] = {(int)n1.x, (int)n1.y, (int)n1.z, (int)n1.w};
-                const int kmin = min(min(key[0], key[1]), min(key[2], key[3]));
-                if (kmin != 0x7fffffff) {
-                    // nearest child next; the other hit children go to the stack
-                    const int idxN = kmin & 3;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (key[k] != 0x7fffffff && k != idxN) {
-                            if (sp < kWfLdsStack) stack[sp * 64] = refs[k]; else ovf[(sp - kWfLdsStack) * ovfStride] = refs[k];
-                            sp++;
-                        }
-                    }
-                    cur = idxN == 0 ? refs[0] : (idxN == 1 ? refs[1] : (idxN == 2 ? refs[2] : refs[3]));
+                // sort the four keys (5 compare-exchanges); the child index rides in their low bits
+                int k0 = min(key[0], key[1]), k1 = max(key[0], key[1]), k2 = min(key[2], key[3]), k3 = max(key[2], key[3]);
+                { const int a0 = min(k0, k2), a2 = max(k0, k2), a1 = min(k1, k3), a3 = max(k1, k3); k0 = a0; k3 = a3; k1 = min(a1, a2); k2 = max(a1, a2); }
+                auto ref_of = [&](int k) { const int i = k & 3; return i == 0 ? refs[0] : (i == 1 ? refs[1] : (i == 2 ? refs[2] : refs[3])); };
+                if (k0 != 0x7fffffff) {
+                    // nearest child next; the other hit children go to the stack, farthest first
+                    if (k3 != 0x7fffffff) { const int r = ref_of(k3); if (sp < kWfLdsStack) stack[sp * 64] = r; else ovf[(sp - kWfLdsStack) * ovfStride] = r; sp++; }
+                    if (k2 != 0x7fffffff) { const int r = ref_of(k2); if (sp < kWfLdsStack) stack[sp * 64] = r; else ovf[(sp - kWfLdsStack) * ovfStride] = r; sp++; }
+                    if (k1 != 0x7fffffff) { const int r = ref_of(k1); if (sp < kWfLdsStack) stack[sp * 64] = r; else ovf[(sp - kWfLdsStack) * ovfStride] = r; sp++; }
+                    cur = ref_of(k0);
                 } else if (sp == 0) {
                     cur = kDone;
                 } else {
@@ -326,7 +333,17 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 }
                 hitOut[sid] = make_float2(bestT, __int_as_float(bestPrim));
                 hasRay = false;
+                if (STAT) stRays++;
             }
+        }
+    }
+    if (STAT) {
+        // per-lane ray count -> wave total
+        unsigned long long r = stRays;
+        for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
+        if (lane == 0) {
+            atomicAdd(&stat[0], stNodeTrips); atomicAdd(&stat[1], stNodeLanes); atomicAdd(&stat[2], stTriTrips); atomicAdd(&stat[3], stTriLanes);
+            atomicAdd(&stat[4], stRefills); atomicAdd(&stat[5], stRefillLanes); atomicAdd(&stat[6], stNoRayLanes); atomicAdd(&stat[7], r);
         }
     }
 }
@@ -464,6 +481,10 @@ static void carve(char* p, size_t nStreams, int traceBlocks, ptd::WfBuf& b)
 
 const float* ptk_wf_staging(void* work) { return (const float*)work; }
 
+// diagnostic trip counters of wf_trace (8 x u64 in device memory), or null: set per render by pt_api.hip
+static unsigned long long* g_traceStat = nullptr;
+void ptk_wf_set_stat(void* p) { g_traceStat = (unsigned long long*)p; }
+
 // One cohort's pipeline on its own stream.  Blocks the calling host thread until the cohort has
 // drained (it polls the live-stream count every 16..64 iterations).
 static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::DevCamera* cam, ptd::DevParams prm,
@@ -492,6 +513,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     static const int budgetMin = getenv("PTAMD_BM") ? atoi(getenv("PTAMD_BM")) : kWfBudget;
     static const int shadeThreads = getenv("PTAMD_ST") ? atoi(getenv("PTAMD_ST")) : kShadeThreads;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
+    unsigned long long* const traceStat = g_traceStat;
     int it = 0;
     int poll = 16;
     // streams only ever retire, so the live count of the last poll bounds every later one: the shade grid
@@ -502,7 +524,8 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
             const bool timed = trace_ev && it < trace_ev_pairs;
             if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
-            hipLaunchKernelGGL(wf_trace, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift);
+            if (traceStat) hipLaunchKernelGGL(wf_trace<true>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, traceStat);
+            else hipLaunchKernelGGL(wf_trace<false>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, (unsigned long long*)nullptr);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
             hipLaunchKernelGGL(wf_shade, dim3((liveBound + shadeThreads - 1) / shadeThreads), dim3(shadeThreads), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
         }

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Trip statistics of wf_trace (diagnostic build, PTAMD_TSTAT=1): how full the node / triangle trips are."""
+import os, sys
+os.environ["PTAMD_TSTAT"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pathtrace-on-cuda_amd"))
+import numpy as np, torch, ptamd
+kind = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+W, H, passes, spp = (int(x) for x in (sys.argv[2:6] if len(sys.argv) > 5 else (1920, 1080, 2, 32)))
+prims = ptamd.gen_scene(kind, 187)
+nodes, tris, depth = ptamd.build_bvh(prims)
+sc = ptamd.Scene(nodes, tris)
+cam = ptamd.make_camera(W, H); prm = ptamd.default_params(passes=passes, spp_per_pass=spp)
+sc.render(cam, prm); torch.cuda.synchronize()
+nT, nL, tT, tL, rf, rfL, noRay, rays = (float(x) for x in sc.counters())
+trips = nT + tT
+print("rays %.4g  trips/ray: node %.2f (lanes served/trip %.1f)  tri %.2f (lanes/trip %.1f)" % (rays, nL / rays, nL / nT, tL / rays, tL / tT))
+print("wave trips %.4g: node %.1f%% tri %.1f%%;  lanes without a ray per trip %.1f;  useful lane-trips / (64 x trips) = %.3f" %
+      (trips, 100 * nT / trips, 100 * tT / trips, noRay / trips, (nL + tL) / (64 * trips)))
+print("refills %.4g, %.1f rays each; trips per refill %.1f" % (rf, rfL / rf, trips / rf))
