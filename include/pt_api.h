@@ -209,6 +209,10 @@ PT_API int  pt_dbg_math(int32_t device, const float* in, int32_t n, float* out8)
  * [0] rays [1] node records fetched [2] triangle tests [3] sphere tests [4] rays with hit
  * [5] camera paths [6] loop trips of the wave scheduler [7] lane-trips with an active ray */
 PT_API int  pt_last_counters(PtScene* s, int64_t* out8);
+/* Diagnostic (environment PTAMD_TSTAT=1 only): per wf_trace launch of the last render, in 100 MHz ticks:
+ * ~(earliest wave start), ~(earliest time a wave found the ray queue empty; 0 = never), latest wave exit.
+ * With PTAMD_TSTAT=1 pt_last_counters returns wf_trace's trip counters instead of the work counters. */
+PT_API int  pt_dbg_trace_timeline(PtScene* s, int64_t* out3n, int32_t n_launches);
 /* Render path: 1 = queue-driven wavefront pipeline (default: traversal and shading are
  * separate kernels, lanes refill from a ray queue), 0 = the one-kernel state machine,
  * 2 = one persistent launch of workgroup-local pipelines (experimental, slower).

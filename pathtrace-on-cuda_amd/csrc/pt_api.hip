@@ -48,6 +48,8 @@ void pt_set_error(const char* fmt, ...);   // pt_host.cpp
         }                                                                                   \
     } while (0)
 
+static const size_t kCounterBytes = 64 + 2700 * 3 * 8;   // 8 work counters + diagnostic launch timeline (3 x u64 per wf_trace launch)
+
 struct PtScene {
     int device = 0;
     ptd::DevScene dev{};
@@ -214,8 +216,8 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
         return rc;
     }
     HIPCHK(hipMalloc((void**)&sc->d_unit_counter, 64));
-    HIPCHK(hipMalloc(&sc->d_counters, 64));
-    HIPCHK(hipMemset(sc->d_counters, 0, 64));
+    HIPCHK(hipMalloc(&sc->d_counters, kCounterBytes));      // 8 work counters (+ the diagnostic launch timeline of wf_trace)
+    HIPCHK(hipMemset(sc->d_counters, 0, kCounterBytes));
     for (int i = 0; i < PtScene::kEvRing; i++) { HIPCHK(hipEventCreate(&sc->ev[i][0])); HIPCHK(hipEventCreate(&sc->ev[i][1])); }
     HIPCHK(hipHostMalloc((void**)&sc->h_poll, 4 * 64, hipHostMallocDefault));
     for (int i = 0; i < 3; i++) { HIPCHK(hipStreamCreateWithFlags(&sc->xstreams[i], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&sc->ev_join[i], hipEventDisableTiming)); }
@@ -339,7 +341,7 @@ int pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm, float*
         for (int k = 0; k < 4; k++) s->trace_ev_used[k] = 0;
         // diagnostic (PTAMD_TSTAT=1): wf_trace counts its trips and the lanes they serve; read with pt_last_counters
         static const bool kTraceStat = getenv("PTAMD_TSTAT") && atoi(getenv("PTAMD_TSTAT")) != 0;
-        if (kTraceStat) HIPCHK(hipMemsetAsync(s->d_counters, 0, 64, stream));
+        if (kTraceStat) HIPCHK(hipMemsetAsync(s->d_counters, 0, kCounterBytes, stream));
         ptk_wf_set_stat(kTraceStat ? s->d_counters : nullptr);
         HIPCHK(ptk_wf_render(s->device, &s->dev, &c, &d, d_work, kTraceBlocks, s->h_poll, stream, s->xstreams,
                              s->ev[slot][0], s->ev[slot][1], s->ev_fork, s->ev_join, &iters,
@@ -468,6 +470,15 @@ PT_API int pt_set_drain_threshold(PtScene* s, int32_t live_streams)
     return PT_OK;
 }
 // Ask the next pt_render_tiles on this scene to run the counting build of the kernel.
+int pt_dbg_trace_timeline(PtScene* s, int64_t* out3n, int32_t n_launches)
+{
+    if (!s || !out3n || n_launches < 0 || n_launches > 2700) { pt_set_error("pt_dbg_trace_timeline: bad arguments"); return PT_ERR_INVALID; }
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out3n, (const char*)s->d_counters + 64, (size_t)n_launches * 24, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
 PT_API int pt_enable_counters(PtScene* s, int32_t on) { if (!s) return PT_ERR_INVALID; s->count_next = on != 0; return PT_OK; }
 
 // ---- parity hooks ------------------------------------------------------------------------

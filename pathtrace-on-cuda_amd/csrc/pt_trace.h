@@ -109,38 +109,6 @@ PT_DEV void tri_test(const DevScene& sc, int q, const f3& org, const f3& dir, co
     bestT = t; bestPrim = prim;
 }
 
-// The same test for callers that keep the true inverse direction `inv` and its length L instead of
-// the normalised one (wf_trace: the quantised tree is walked in true ray units): the reference's
-// normalised inverse direction is formed only when a triangle is accepted.
-PT_DEV void tri_test_lazy(const DevScene& sc, int q, const f3& org, const f3& dir, const f3& inv, float L, bool degenerate,
-                          float& bestT, int& bestPrim)
-{
-    const float4 a = sc.tri[3 * q], b = sc.tri[3 * q + 1], c = sc.tri[3 * q + 2];
-    const f3 V0(a.x, a.y, a.z), E1(b.x, b.y, b.z), E2(c.x, c.y, c.z);
-    const f3 T = org - V0;
-    const f3 P = cross(dir, E2);
-    const f3 Q = cross(T, E1);
-    const float det = dot(P, E1);
-    if (det < kEps) return;
-    const float invDet = 1.f / det;
-    const float t = dot(Q, E2) * invDet;
-    if (t < 0.f || t > bestT) return;
-    const float u = dot(P, T);
-    if (u < 0.f || u > det) return;
-    const float v = dot(Q, dir);
-    if (v < 0.f || (v + u) > det) return;
-    const int prim = __float_as_int(a.w);
-    if (!(t < bestT || prim > bestPrim)) return;
-    if (!degenerate) {
-        const int leaf = __float_as_int(b.w);
-        const float4 l0 = sc.leafbox[2 * leaf], l1 = sc.leafbox[2 * leaf + 1];
-        const f3 invD = inv / L;                                             // Normalize(inv(dir)), CudaUtil.cuh:70
-        float tn;
-        if (!box_test(l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, org, invD, __builtin_inff(), tn)) return;
-    }
-    bestT = t; bestPrim = prim;
-}
-
 // Sphere::hit root selection, include/CudaPrimitive.cuh:255-272.
 PT_DEV bool sphere_root(const f3& center, float rad, const f3& org, const f3& dir, float tmax, float& root)
 {

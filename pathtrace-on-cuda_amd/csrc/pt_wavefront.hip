@@ -117,9 +117,11 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
 // STAT: a diagnostic build that also counts trips and the lanes they serve (pt_last_counters; PTAMD_TSTAT=1).
 template <bool STAT>
 __global__ __launch_bounds__(256, 8)
-void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift,
-              unsigned long long* stat)
+void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift, int triTrig,
+              unsigned long long* stat, int statLaunch)
 {
+    const unsigned long long stT0 = STAT ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz
+    unsigned long long stTExh = 0;
     unsigned long long stNodeTrips = 0, stNodeLanes = 0, stTriTrips = 0, stTriLanes = 0, stRefills = 0, stRefillLanes = 0, stNoRayLanes = 0, stRays = 0;
     __shared__ int lds_stack[4][kWfLdsStack * 64];
     // one queue index space: [0, nPath) are path rays, [nPath, nPath + nShadow) shadow rays
@@ -146,11 +148,14 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
     bool hasRay = false;
     // per-ray registers
     uint32_t sid = 0;
-    f3 org(0.f, 0.f, 0.f), dir(0.f, 0.f, 1.f), inv(0.f, 0.f, 0.f);   // inv: 1/dir, clamped to +-1e30 (see the node step)
-    float bestT = 0.f, invLen = 0.f, stopBelow = 0.f;
+    // inv: the reference's Normalize(inv(dir)) (CudaUtil.cuh:70) — what its leaf-box test uses, and a perfectly good
+    // inverse direction for the tree walk, which then measures t in units of 1/|inv(dir)|; cscale converts the
+    // closest hit into those units.  Degenerate rays (a zero direction component): 1/dir clamped to +-1e30, true units.
+    f3 org(0.f, 0.f, 0.f), dir(0.f, 0.f, 1.f), inv(0.f, 0.f, 0.f);
+    float bestT = 0.f, cscale = 0.f, stopBelow = 0.f;
     int bestPrim = -1, cur = kDone, sp = 0, steps = 0;
+    int pend = 0;        // a leaf this ray has reached but not yet tested (0 = none): see "postponed leaves" below
     bool degenerate = false, shadow = false;
-    float2* hitOut = b.hit[0];
 
     for (;;) {
         // ---- hand new rays to idle lanes (ballot + mbcnt compaction) ----
@@ -174,7 +179,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     if (start < hi - lo) { chunkPos = lo + start; chunkEnd = (hi - lo - start > want) ? chunkPos + want : hi; seenLeft = hi - lo - start; break; }
                     seenLeft = 0xffffffffu;
                     shard = (shard + 1) % kWfShards;
-                    if (++shardsTried >= kWfShards) { exhausted = true; break; }
+                    if (++shardsTried >= kWfShards) { exhausted = true; if (STAT) stTExh = __builtin_amdgcn_s_memrealtime(); break; }
                 }
             }
             if (!exhausted) {
@@ -187,19 +192,23 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                         const uint32_t q = chunkPos + r;
                         shadow = q >= nPath;
                         sid = shadow ? b.rq[1][q - nPath] : b.rq[0][q];
-                        hitOut = shadow ? b.hit[1] : b.hit[0];
                         const float4 o = (shadow ? b.ray_o[1] : b.ray_o[0])[sid], d = (shadow ? b.ray_d[1] : b.ray_d[0])[sid];
                         org = f3(o.x, o.y, o.z); dir = f3(d.x, d.y, d.z);
                         inv = f3(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);                     // inv(), CudaUtil.cuh:60-63
-                        invLen = __builtin_sqrtf(inv.x * inv.x + inv.y * inv.y + inv.z * inv.z);   // |inv(dir)| of Normalize(inv(dir)), :70
-                        degenerate = !(invLen < __builtin_inff());
-                        // the tree walk wants a finite inverse direction (a non-degenerate ray's is untouched: |inv| < 1.9e19)
-                        inv.x = (__builtin_fabsf(inv.x) <= 1e30f) ? inv.x : __builtin_copysignf(1e30f, dir.x);
-                        inv.y = (__builtin_fabsf(inv.y) <= 1e30f) ? inv.y : __builtin_copysignf(1e30f, dir.y);
-                        inv.z = (__builtin_fabsf(inv.z) <= 1e30f) ? inv.z : __builtin_copysignf(1e30f, dir.z);
+                        const float L = __builtin_sqrtf(inv.x * inv.x + inv.y * inv.y + inv.z * inv.z);
+                        degenerate = !(L < __builtin_inff());
+                        if (!degenerate) {
+                            inv = inv / L;                                                   // Normalize(inv(dir)), :70
+                            cscale = __builtin_amdgcn_rcpf(L) * 1.0000019f;                  // 1/L, rounded up a little: the cull must not bite early
+                        } else {
+                            inv.x = (__builtin_fabsf(inv.x) <= 1e30f) ? inv.x : __builtin_copysignf(1e30f, dir.x);
+                            inv.y = (__builtin_fabsf(inv.y) <= 1e30f) ? inv.y : __builtin_copysignf(1e30f, dir.y);
+                            inv.z = (__builtin_fabsf(inv.z) <= 1e30f) ? inv.z : __builtin_copysignf(1e30f, dir.z);
+                            cscale = 1.0000019f;
+                        }
                         stopBelow = shadow ? (o.w - 1.0f) - 5e-4f : -__builtin_inff();
                         steps = 0;
-                        const float2 prev = hitOut[sid];
+                        const float2 prev = (shadow ? b.hit[1] : b.hit[0])[sid];
                         const int pp = __float_as_int(prev.y);
                         if (pp <= -2) {
                             // resume a suspended traversal
@@ -212,6 +221,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                         } else {
                             bestT = o.w; bestPrim = -1; cur = 0; sp = 0;
                         }
+                        pend = 0;
                         hasRay = true;
                     }
                 }
@@ -232,9 +242,10 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     const uint32_t rec = atomicAdd(&b.cnt[slot].nSusp, 1u);
                     if (rec < b.suspCap) {
                         int* r = suspOut + (size_t)rec * kSuspInts;
+                        if (pend != 0) { if (sp < kWfLdsStack) stack[sp * 64] = pend; else ovf[(sp - kWfLdsStack) * ovfStride] = pend; sp++; pend = 0; }
                         r[0] = cur; r[1] = sp; r[2] = __float_as_int(bestT); r[3] = bestPrim;
                         for (int k = 0; k < sp; k++) r[4 + k] = (k < kWfLdsStack) ? stack[k * 64] : ovf[(k - kWfLdsStack) * ovfStride];
-                        hitOut[sid] = make_float2(bestT, __int_as_float(-2 - (int)rec));
+                        (shadow ? b.hit[1] : b.hit[0])[sid] = make_float2(bestT, __int_as_float(-2 - (int)rec));
                         hasRay = false;
                         cur = kDone;
                     } else {
@@ -242,11 +253,18 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     }
                 }
             }
-            // wave vote: run ONE of the two code paths this trip — the one more lanes are waiting for
+            // Wave vote with postponed leaves.  A ray that reaches a leaf does not wait for a triangle trip:
+            // it parks the leaf in `pend` and goes on with the next entry of its stack; only a ray that
+            // reaches a SECOND leaf (or has nothing else left) needs a triangle trip.  A triangle trip
+            // then serves every ray with a parked leaf, a node trip every ray that still holds a node:
+            // both kinds of trip run fuller than when each ray blocked at its first leaf
+            // (59 % of lane-trips useful before).  Order of tests does not matter to the result: the tie rule
+            // makes the closest hit independent of it; parked leaves only delay the tightening of the cull.
             const int nNode = __builtin_popcountll(__ballot(cur >= 0));
-            const int nTri = __builtin_popcountll(__ballot(hasRay && cur < 0 && cur != kDone));
-            const bool doNode = nNode >= nTri;
-            const bool doTri = !doNode;
+            const int nTri = __builtin_popcountll(__ballot(hasRay && pend != 0));
+            const int nBlk = __builtin_popcountll(__ballot(hasRay && pend != 0 && cur < 0));
+            const bool doTri = nTri > 0 && (nTri >= triTrig || nBlk >= nNode);
+            const bool doNode = !doTri;
             if (STAT) {
                 if (doNode) { stNodeTrips++; stNodeLanes += nNode; } else { stTriTrips++; stTriLanes += nTri; }
                 stNoRayLanes += 64 - __builtin_popcountll(__ballot(hasRay));
@@ -254,8 +272,8 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
             if (doNode && cur >= 0) {
                 steps++;
                 // ---- one 4-wide node: conservative slab test of its four quantised child boxes ----
-                // Child box = origin + 2^e * q.  Along each axis t(q) = q*A + B with A = 2^e / dir and
-                // B = (origin - org) / dir; both are widened by `sl` (2^-20 of their magnitudes, ~16 ulps),
+                // Child box = origin + 2^e * q.  Along each axis t(q) = q*A + B with A = 2^e * inv and
+                // B = (origin - org) * inv; both are widened by `sl` (2^-20 of their magnitudes, ~16 ulps),
                 // the near/far bytes are picked by the sign of the direction once per node (all four children
                 // of a coordinate share a dword), and the far side is cut at the closest hit.  The boxes only
                 // steer the search — acceptance is Triangle::hit + the reference's leaf box — so all that
@@ -279,7 +297,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 const uint32_t nqx = px ? n2.x : n2.w, fqx = px ? n2.w : n2.x;   // lo.x = n2.x, hi.x = n2.w
                 const uint32_t nqy = py ? n2.y : n3.x, fqy = py ? n3.x : n2.y;   // lo.y = n2.y, hi.y = n3.x
                 const uint32_t nqz = pz ? n2.z : n3.y, fqz = pz ? n3.y : n2.z;   // lo.z = n2.z, hi.z = n3.y
-                const float cullT = bestT * 1.00000095f;
+                const float cullT = bestT * cscale;
                 int key[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -310,28 +328,36 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     sp--;
                     cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride];
                 }
-            } else if (doTri && hasRay && cur < 0 && cur != kDone) {
-                // ---- one triangle of the leaf this lane holds ----
-                const int code = ~cur, first = code >> 3, cnt = code & 7;
-                bool pop = true;
-                if (cnt > 0) {
-                    tri_test_lazy(sc, first, org, dir, inv, invLen, degenerate, bestT, bestPrim);
-                    if (bestPrim >= 0 && bestT < stopBelow) { cur = kDone; pop = false; }
-                    else if (cnt > 1) { cur = ~(((first + 1) << 3) | (cnt - 1)); pop = false; }
+                if (cur < 0 && cur != kDone && pend == 0) {
+                    // park the leaf, carry on with the next stack entry
+                    pend = cur;
+                    if (sp == 0) cur = kDone;
+                    else { sp--; cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride]; }
                 }
-                if (pop) {
+            } else if (doTri && hasRay && pend != 0) {
+                // ---- one triangle of the parked leaf ----
+                const int code = ~pend, first = code >> 3, cnt = code & 7;
+                pend = 0;
+                if (cnt > 0) {
+                    tri_test(sc, first, org, dir, inv, degenerate, bestT, bestPrim);
+                    if (bestPrim >= 0 && bestT < stopBelow) { cur = kDone; sp = 0; }          // shadow ray: any occluder in front of the light will do
+                    else if (cnt > 1) pend = ~(((first + 1) << 3) | (cnt - 1));
+                }
+                if (pend == 0 && cur < 0 && cur != kDone) {
+                    // the ray was waiting with a second leaf: park that one, take the next stack entry
+                    pend = cur;
                     if (sp == 0) cur = kDone;
                     else { sp--; cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride]; }
                 }
             }
-            if (hasRay && cur == kDone) {
+            if (hasRay && cur == kDone && pend == 0) {
                 // spheres, in order, against the triangles' closest t (CudaUtil.cuh:137-145)
                 for (int s = 0; s < sc.n_spheres; s++) {
                     const float4 c = sc.spheres[4 * s];
                     float root;
                     if (sphere_root(f3(c.x, c.y, c.z), c.w, org, dir, bestT, root)) { bestT = root; bestPrim = sc.n_tris + s; }
                 }
-                hitOut[sid] = make_float2(bestT, __int_as_float(bestPrim));
+                (shadow ? b.hit[1] : b.hit[0])[sid] = make_float2(bestT, __int_as_float(bestPrim));
                 hasRay = false;
                 if (STAT) stRays++;
             }
@@ -343,6 +369,9 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
         for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
         if (lane == 0) {
             atomicAdd(&stat[0], stNodeTrips); atomicAdd(&stat[1], stNodeLanes); atomicAdd(&stat[2], stTriTrips); atomicAdd(&stat[3], stTriLanes);
+            // launch timeline (100 MHz ticks): earliest wave start, earliest "queue empty", latest wave exit
+            unsigned long long* tl = stat + 8 + 3 * (size_t)statLaunch;
+            atomicMax(&tl[0], ~stT0); if (stTExh) atomicMax(&tl[1], ~stTExh); atomicMax(&tl[2], (unsigned long long)__builtin_amdgcn_s_memrealtime());
             atomicAdd(&stat[4], stRefills); atomicAdd(&stat[5], stRefillLanes); atomicAdd(&stat[6], stNoRayLanes); atomicAdd(&stat[7], r);
         }
     }
@@ -512,6 +541,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     static const int budgetShift = getenv("PTAMD_BS") ? atoi(getenv("PTAMD_BS")) : 14;
     static const int budgetMin = getenv("PTAMD_BM") ? atoi(getenv("PTAMD_BM")) : kWfBudget;
     static const int shadeThreads = getenv("PTAMD_ST") ? atoi(getenv("PTAMD_ST")) : kShadeThreads;
+    static const int triTrig = getenv("PTAMD_TT") ? atoi(getenv("PTAMD_TT")) : 64;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
     unsigned long long* const traceStat = g_traceStat;
     int it = 0;
@@ -524,8 +554,8 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
             const bool timed = trace_ev && it < trace_ev_pairs;
             if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
-            if (traceStat) hipLaunchKernelGGL(wf_trace<true>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, traceStat);
-            else hipLaunchKernelGGL(wf_trace<false>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, (unsigned long long*)nullptr);
+            if (traceStat) hipLaunchKernelGGL(wf_trace<true>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, traceStat, it < 2700 ? it : 2699);
+            else hipLaunchKernelGGL(wf_trace<false>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, (unsigned long long*)nullptr, 0);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
             hipLaunchKernelGGL(wf_shade, dim3((liveBound + shadeThreads - 1) / shadeThreads), dim3(shadeThreads), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
         }

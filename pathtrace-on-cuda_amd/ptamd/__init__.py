@@ -77,6 +77,7 @@ API = [
     ("pt_dbg_rng", C.c_int, [C.c_int32, C.c_uint64, C.c_int32, _P, _P]),
     ("pt_dbg_math", C.c_int, [C.c_int32, _P, C.c_int32, _P]),
     ("pt_last_counters", C.c_int, [_P, _P]),
+    ("pt_dbg_trace_timeline", C.c_int, [_P, _P, C.c_int32]),
     ("pt_enable_counters", C.c_int, [_P, C.c_int32]),
     ("pt_set_mode", C.c_int, [_P, C.c_int32]),
     ("pt_enable_trace_timing", C.c_int, [_P, C.c_int32]),
@@ -280,6 +281,15 @@ class Scene:
     def counters(self):
         out = np.zeros(8, np.int64)
         _check(lib().pt_last_counters(self._h, _ptr(out)), "pt_last_counters")
+        return out
+
+    def trace_timeline(self, n_launches):
+        """Diagnostic (PTAMD_TSTAT=1): per wf_trace launch (start, queue-empty, end) in 100 MHz ticks; 0 = not recorded."""
+        raw = np.zeros((int(n_launches), 3), np.int64)
+        _check(lib().pt_dbg_trace_timeline(self._h, _ptr(raw), int(n_launches)), "pt_dbg_trace_timeline")
+        out = raw.copy()
+        out[:, 0] = np.where(raw[:, 0] != 0, ~raw[:, 0], 0)
+        out[:, 1] = np.where(raw[:, 1] != 0, ~raw[:, 1], 0)
         return out
 
     def raycast(self, rays8):

@@ -18,3 +18,13 @@ print("rays %.4g  trips/ray: node %.2f (lanes served/trip %.1f)  tri %.2f (lanes
 print("wave trips %.4g: node %.1f%% tri %.1f%%;  lanes without a ray per trip %.1f;  useful lane-trips / (64 x trips) = %.3f" %
       (trips, 100 * nT / trips, 100 * tT / trips, noRay / trips, (nL + tL) / (64 * trips)))
 print("refills %.4g, %.1f rays each; trips per refill %.1f" % (rf, rfL / rf, trips / rf))
+it = sc.last_iterations()
+tl = sc.trace_timeline(min(it, 2700)).astype(np.float64)
+ok = (tl[:, 0] != 0) & (tl[:, 2] != 0)
+tl = tl[ok]
+dur = (tl[:, 2] - tl[:, 0]) / 100.0                       # microseconds
+exh = np.where(tl[:, 1] != 0, (tl[:, 1] - tl[:, 0]) / 100.0, dur)
+print("launches %d: mean duration %.1f us (first wave start -> last wave exit); queue first seen empty after %.1f us; drain after that %.1f us" %
+      (len(tl), dur.mean(), exh.mean(), (dur - exh).mean()))
+for lo, hi in ((0, 50), (len(tl) // 4, len(tl) // 4 + 50), (len(tl) // 2, len(tl) // 2 + 50), (3 * len(tl) // 4, 3 * len(tl) // 4 + 50)):
+    print("  launches %4d-%4d: duration %.1f us, queue empty at %.1f us" % (lo, hi, dur[lo:hi].mean(), exh[lo:hi].mean()))
