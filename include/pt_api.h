@@ -214,9 +214,8 @@ PT_API int  pt_last_counters(PtScene* s, int64_t* out8);
  * With PTAMD_TSTAT=1 pt_last_counters returns wf_trace's trip counters instead of the work counters. */
 PT_API int  pt_dbg_trace_timeline(PtScene* s, int64_t* out3n, int32_t n_launches);
 /* Render path: 1 = queue-driven wavefront pipeline (default: traversal and shading are
- * separate kernels, lanes refill from a ray queue), 0 = the one-kernel state machine,
- * 2 = one persistent launch of workgroup-local pipelines (experimental, slower).
- * All produce bit-identical frames.  Environment PTAMD_MODE overrides the default.
+ * separate kernels, lanes refill from a ray queue), 0 = the one-kernel state machine.
+ * Both produce bit-identical frames.  Environment PTAMD_MODE overrides the default.
  * pt_last_iterations: bounce iterations the pipeline needed for the last render. */
 PT_API int  pt_set_mode(PtScene* s, int32_t mode);
 /* Per-launch timing of the traversal kernel (wf_trace, mode 1): pt_enable_trace_timing makes

@@ -26,9 +26,6 @@ hipError_t ptk_dbg_raycast(const ptd::DevScene*, const float*, int, float*, int*
 hipError_t ptk_dbg_bxdf(int, const float*, int, float*, hipStream_t);
 hipError_t ptk_dbg_rng(unsigned long long, int, uint32_t*, float*, hipStream_t);
 hipError_t ptk_dbg_math(const float*, int, float*, hipStream_t);
-size_t ptk_pw_work_bytes(size_t nUnits, int numCUs);
-const float* ptk_pw_staging(void* work);
-hipError_t ptk_pw_render(const ptd::DevScene*, const ptd::DevCamera*, const ptd::DevParams*, void*, int, hipStream_t, hipEvent_t, hipEvent_t);
 size_t ptk_wf_work_bytes(size_t nUnits, int traceBlocks);
 int ptk_wf_cohorts(size_t nUnits);
 const float* ptk_wf_staging(void* work);
@@ -223,7 +220,7 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     for (int i = 0; i < 3; i++) { HIPCHK(hipStreamCreateWithFlags(&sc->xstreams[i], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&sc->ev_join[i], hipEventDisableTiming)); }
     HIPCHK(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
     // environment overrides of the per-scene defaults (the same settings have C-ABI setters: pt_set_mode, pt_set_drain_threshold)
-    if (const char* m = getenv("PTAMD_MODE")) { const int v = atoi(m); if (v >= 0 && v <= 2) sc->mode = v; }
+    if (const char* m = getenv("PTAMD_MODE")) { const int v = atoi(m); if (v >= 0 && v <= 1) sc->mode = v; }
     if (const char* m = getenv("PTAMD_DRAIN")) sc->drain_below = atoi(m);
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -298,9 +295,7 @@ int64_t pt_work_bytes(const PtCamera* cam, const PtParams* prm)
     if (fill_params(cam, prm, d)) return -1;
     const int64_t mega = (int64_t)d.n_tiles_local * ptd::kTilePixels * 3 * 4 * prm->passes;
     const int64_t wave = (int64_t)ptk_wf_work_bytes((size_t)d.n_units, kTraceBlocks);
-    const int64_t pers = (int64_t)ptk_pw_work_bytes((size_t)d.n_units, 256);
-    int64_t m = mega > wave ? mega : wave;
-    return m > pers ? m : pers;
+    return mega > wave ? mega : wave;
 }
 
 int pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm, float* d_tiles, void* d_work, void* hip_stream)
@@ -326,13 +321,6 @@ int pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm, float*
     HIPCHK(hipSetDevice(s->device));
     const int slot = s->ev_count % PtScene::kEvRing;
     const long long perPass = (long long)d.n_tiles_local * ptd::kTilePixels * 3;
-    if (s->mode == 2 && !s->count_next) {
-        // persistent workgroup-local pipeline (pt_persist.hip): one asynchronous launch
-        HIPCHK(ptk_pw_render(&s->dev, &c, &d, d_work, s->num_cus > 256 ? 256 : s->num_cus, stream, s->ev[slot][0], s->ev[slot][1]));
-        s->ev_count++;
-        HIPCHK(ptk_sum_passes(ptk_pw_staging(d_work), d.passes, perPass, d_tiles, stream));
-        return PT_OK;
-    }
     if (s->mode == 1 && !s->count_next) {
         // queue-driven pipeline (pt_wavefront.hip); polls the live-stream count, so it returns once the render has drained
         int iters = 0;
@@ -461,7 +449,7 @@ PT_API int pt_trace_timing(PtScene* s, double* sum_ms, int32_t* launches, double
     *sum_ms = sum; *launches = total; if (max_ms) *max_ms = mx;
     return PT_OK;
 }
-PT_API int pt_set_mode(PtScene* s, int32_t mode) { if (!s || mode < 0 || mode > 2) { pt_set_error("pt_set_mode: bad argument"); return PT_ERR_INVALID; } s->mode = mode; return PT_OK; }
+PT_API int pt_set_mode(PtScene* s, int32_t mode) { if (!s || mode < 0 || mode > 1) { pt_set_error("pt_set_mode: mode must be 0 or 1"); return PT_ERR_INVALID; } s->mode = mode; return PT_OK; }
 PT_API int pt_last_iterations(PtScene* s) { return s ? s->last_iters : -1; }
 PT_API int pt_set_drain_threshold(PtScene* s, int32_t live_streams)
 {

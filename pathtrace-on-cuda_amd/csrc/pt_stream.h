@@ -10,38 +10,45 @@
 namespace ptd {
 
 enum : uint32_t {
-    F_REFR = 1,      // bRefracted (loop-carried, Q8)
-    F_NEEOK = 2,     // !isnan(brdfcos) of the pending NEE term
-    F_SHADOW = 4,    // a shadow ray was traced for this stream: NEE term pending
-    F_PATH = 8,      // a path ray was traced for this stream
-    F_NEWPATH = 16,  // that path ray is the NEXT sample's camera ray: retire the old path first
+    F_REFR = 1,       // bRefracted of the current sample (loop-carried, Q8)
+    F_NEEOK = 2,      // !isnan(brdfcos) of the current sample's pending NEE term
+    F_SHADOW = 4,     // the current sample has a pending NEE term: shadow ray (kind 1) traced
+    F_PATH = 8,       // the current sample's path ray (kind 0) traced
+    F_PRIMARY = 16,   // that path ray is the pixel's camera ray (first iteration only): its hit is cached
+    F_SHADOWA = 32,   // an OLDER sample, already closed, still has its last NEE term pending: shadow ray (kind 2) traced
+    F_NEEOKA = 64,    // !isnan(brdfcos) of that term
+    F_CUR = 128,      // a current sample exists (started, not yet added to the pixel)
 };
+constexpr int kRayKinds = 3;     // 0 path, 1 shadow of the current sample, 2 shadow of the older closed sample
 
 struct WfCounters {      // one slot per iteration parity (3 rotating slots); every hot word on its own 128-B line
     uint32_t nActive, padA[31];
-    uint32_t nPath, padB[31];
-    uint32_t nShadow, padC[31];
+    uint32_t nRays[kRayKinds][32];                 // [kind][0]: rays queued per kind
     uint32_t nSusp, padD[31];
     struct { uint32_t v, pad[31]; } head[16];     // sharded ray-queue heads, one 128-B line each
 };
 constexpr int kWfShards = 16;
-constexpr int kWfSlotBytes = 2560;
+constexpr int kWfSlotBytes = 128 * (2 + kRayKinds + 16);
 static_assert(sizeof(WfCounters) == kWfSlotBytes, "counter slot layout");
 
 struct WfBuf {
     uint4* rng0;         // x0 x1 x2 x3
-    uint4* rng1;         // x4 d | samplesLeft<<16 | depth<<8 | refractCnt | flags
-    float4* weight;      // weight.xyz | cosA
-    float4* rad;         // radiance.xyz | denom
+    uint4* rng1;         // x4 d | samplesToStart<<16 | depth<<8 | refractCnt | flags
+    float4* weight;      // weight.xyz | cosA of the pending NEE term
+    float4* rad;         // radiance.xyz | denom of the pending NEE term
     float4* pix;         // pixelColor.xyz
-    float4* dir0;        // camera ray direction of this pixel & pass
+    float4* dir0;        // camera ray direction of this pixel & pass (every sample of the pass shares it, Q2)
+    float2* hit0;        // its closest hit, traced once: (t, primitive)
     float4* wb;          // weight*brdfcos of the pending NEE term
     float4* lp;          // sampled light point of the pending NEE term
-    float4* ray_o[2];    // [0] path, [1] shadow: org.xyz | tmax
-    float4* ray_d[2];    // dir.xyz
-    float2* hit[2];      // t | primitive index (int bits)
-    uint32_t* active[2]; // live stream ids, ping-pong
-    uint32_t* rq[2];     // ray queues (stream ids): [0] path, [1] shadow
+    float4* radA;        // older closed sample: radiance.xyz | denom
+    float4* wbA;         //                      weight*brdfcos | cosA
+    float4* lpA;         //                      light point
+    float4* ray_o[kRayKinds];    // org.xyz | tmax
+    float4* ray_d[kRayKinds];    // dir.xyz
+    float2* hit[kRayKinds];      // t | primitive index (int bits); prim <= -2: traversal suspended, record -2-prim
+    uint32_t* active[2];         // live stream ids, ping-pong
+    uint32_t* rq[kRayKinds];     // ray queues (stream ids)
     WfCounters* cnt;     // [3]
     float* staging;      // per-pass means, [stream][3]
     int* ovf;            // traversal stack overflow (entries >= kWfLdsStack), [level][thread]
@@ -50,7 +57,7 @@ struct WfBuf {
 };
 
 // StartRender prologue for one pixel & pass (srcs/pathtracer.cu:70-74): seeds the RNG, draws the
-// jittered camera direction and writes the initial state of slot `slot`.
+// jittered camera direction and queues the camera ray, whose hit all samples of the pass share.
 PT_DEV void init_stream(const DevCamera& cam, const DevParams& prm, const WfBuf& b, uint32_t slot, int px, int py, int pass)
 {
     const f3 camF(cam.forward[0], cam.forward[1], cam.forward[2]);
@@ -66,59 +73,85 @@ PT_DEV void init_stream(const DevCamera& cam, const DevParams& prm, const WfBuf&
     const f3 direction = normalize(camF + offR + offU);      // GetPixelDirection, pathtracer.cu:33-40
     const f3 d0 = normalize(direction);                      // Ray ctor normalises again, CudaRay.cuh:12
     b.rng0[slot] = make_uint4(rng.x0, rng.x1, rng.x2, rng.x3);
-    b.rng1[slot] = make_uint4(rng.x4, rng.d, ((uint32_t)prm.spp_per_pass << 16), F_PATH);
+    b.rng1[slot] = make_uint4(rng.x4, rng.d, ((uint32_t)prm.spp_per_pass << 16), F_PATH | F_PRIMARY);
     b.weight[slot] = make_float4(1.f, 1.f, 1.f, 0.f);
     b.rad[slot] = make_float4(0.f, 0.f, 0.f, 1.f);
     b.pix[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     b.dir0[slot] = make_float4(d0.x, d0.y, d0.z, 0.f);
     b.ray_o[0][slot] = make_float4(cam.pos[0], cam.pos[1], cam.pos[2], 999999.f);
     b.ray_d[0][slot] = make_float4(d0.x, d0.y, d0.z, 0.f);
-    b.hit[0][slot] = make_float2(0.f, __int_as_float(-1));
-    b.hit[1][slot] = make_float2(0.f, __int_as_float(-1));
+    for (int k = 0; k < kRayKinds; k++) b.hit[k][slot] = make_float2(0.f, __int_as_float(-1));
 }
 
 // ---------------------------------------------------------------------------------------
-// One bounce of one stream — the body of GetColor_iter's loop (include/CudaUtil.cuh:216-380)
-// plus StartRender's sample-loop bookkeeping (srcs/pathtracer.cu:77-81) — on a register-resident
-// stream state.  Shared by wf_shade (state in HBM, one bounce per launch) and wf_drain (state in
-// registers, runs a stream to its end).
+// One step of one stream.
+//
+// The reference runs, per pixel and pass, NUM_SAMPLE paths one after the other
+// (srcs/pathtracer.cu:77-81), each a loop of bounces (GetColor_iter, include/CudaUtil.cuh:216-380):
+// closest hit -> emission -> NEE sample + shadow ray -> BSDF sample -> roulette.  A stream keeps
+// that order of random draws and of floating-point additions, but overlaps what does not depend
+// on each other:
+//   * the camera ray is the same for every sample of the pass (Q2), so it is traced once and its
+//     hit cached; a new sample starts directly with the shading of that hit;
+//   * when a path ends, only its last NEE term is still waiting for a shadow ray.  The next
+//     sample starts IN THE SAME STEP (its random draws simply follow), and the closed sample's
+//     term rides along in slot "A" until the shadow ray is back, one step later; only then is the
+//     closed sample added to the pixel — before anything of the newer one, so pixelColor sees
+//     the samples in order.
+// A step therefore shades up to two hits (the current path's, then the next sample's first) and
+// leaves at most three rays to trace: path, shadow, shadow A.  Per sample it takes (bounces - 1)
+// steps instead of `bounces`.
 // ---------------------------------------------------------------------------------------
 struct SState {
     Rng rng;
-    int samplesLeft, depth, refractCnt;
-    uint32_t flags;                 // F_* of the rays that were traced for this bounce
+    int toStart, depth, refractCnt;
+    uint32_t flags;                 // F_* of the rays that were traced for this step
     f3 weight, radiance;
-    f3 pixelColor; bool pixLoaded;  // loaded lazily: only a retiring path touches it
-    float cosA, denom;              // pending NEE term ...
+    f3 pixelColor; bool pixLoaded;  // loaded lazily: only a closing sample touches it
+    float cosA, denom;              // pending NEE term of the current sample ...
     f3 wb, lightP;                  // ... weight*brdfcos, sampled light point
     f3 pathO, pathD;                // path ray (traced if F_PATH)
     f3 shO, shD; float shTmax;      // shadow ray (traced if F_SHADOW)
+    // The older closed sample (slot A: radiance, pending NEE term, shadow ray) never sits in registers across the
+    // step: shade_step reads it where it is consumed and writes the new one where it is produced.
 };
 
-// Returns true when the stream has finished its last sample.  On return st.flags describes the
-// rays to trace next (F_PATH / F_SHADOW / F_NEWPATH) and the ray fields hold them.
-PT_DEV bool shade_step(const DevScene& sc, const DevCamera& cam, const DevParams& prm, SState& st,
-                       float2 hitP, float2 hitS, const float4* __restrict__ pixPtr, const float4* __restrict__ dir0Ptr)
+// Returns true when the stream has added its last sample to the pixel.  On return st.flags
+// describes the rays to trace next and the ray fields hold them.
+PT_DEV bool shade_step(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const WfBuf& b, uint32_t sid, SState& st,
+                       float2 hitP, float2 hitS, float2 hitA)
 {
+    const float4* __restrict__ pixPtr = &b.pix[sid];
+    const float4* __restrict__ dir0Ptr = &b.dir0[sid];
+    float2* __restrict__ hit0Ptr = &b.hit0[sid];
     const uint32_t flags = st.flags;
     bool bRefracted = (flags & F_REFR) != 0;
     const int Nl = sc.n_lights;
-    // ---- 0. the scene fetches of the bounce, issued together ----
-    // The path hit's surface record (one 192-B record: no index chasing), the shadow hit's emittance and
-    // the light the NEE draw will pick (its random word is peeked) are requested up front with clamped
-    // indices instead of branches, so the compiler can keep them all in flight.  The two per-pixel
-    // values a retiring path needs stay lazy: ~40 % of the steps use them, and the kernel is limited by
-    // memory throughput (its time does not change between 2, 3 and 4 waves/SIMD), not by fetch depth.
-    const int primP = (flags & F_PATH) ? __float_as_int(hitP.y) : -1;
     const int primS = (flags & F_SHADOW) ? __float_as_int(hitS.y) : -1;
-    const bool triP = primP >= 0 && primP < sc.n_tris;
-    SurfRec rec;
-    load_surf(sc, triP ? primP : 0, rec);
+    const int primA = (flags & F_SHADOWA) ? __float_as_int(hitA.y) : -1;
+    // scene fetches that do not depend on anything computed below, issued together
     const float4 emS = tri_emit4(sc, (primS >= 0 && primS < sc.n_tris) ? primS : 0);
-    Rng peek = st.rng;
-    const int li = (int)(peek.next() % (uint32_t)Nl);
-    const float4 l0 = sc.lights[4 * li], l1 = sc.lights[4 * li + 1], l2 = sc.lights[4 * li + 2], l3 = sc.lights[4 * li + 3];
-    // ---- 1. pending NEE term (GetLightColor tail + CudaUtil.cuh:271-272) ----
+    const float4 emA = tri_emit4(sc, (primA >= 0 && primA < sc.n_tris) ? primA : 0);
+    float2 h0 = hitP;
+    if (!(flags & F_PRIMARY)) h0 = *hit0Ptr;
+
+    auto add_to_pixel = [&](const f3& r) {                                  // pathtracer.cu:79
+        if (!st.pixLoaded) { const float4 pq = *pixPtr; st.pixelColor = f3(pq.x, pq.y, pq.z); st.pixLoaded = true; }
+        st.pixelColor += r;
+    };
+    // ---- a. the older closed sample: its last NEE term, then it joins the pixel ----
+    if (flags & F_SHADOWA) {
+        const float4 ra = b.radA[sid], wa = b.wbA[sid], la = b.lpA[sid], ao = b.ray_o[2][sid], ad = b.ray_d[2][sid];
+        f3 radA(ra.x, ra.y, ra.z);
+        f3 Le(0.f, 0.f, 0.f);
+        if (primA >= 0) {
+            const f3 hp = f3(ao.x, ao.y, ao.z) + hitA.x * f3(ad.x, ad.y, ad.z);
+            if (length(hp - f3(la.x, la.y, la.z)) < kEps) Le = (primA < sc.n_tris) ? f3(emA.x, emA.y, emA.z) : prim_emittance(sc, primA);
+        }
+        if (flags & F_NEEOKA) radA += ((f3(wa.x, wa.y, wa.z) * Le) * wa.w) / ra.w;      // GetLightColor tail + CudaUtil.cuh:271-272
+        add_to_pixel(radA);
+    }
+    // ---- b. pending NEE term of the current sample ----
     if (flags & F_SHADOW) {
         f3 Le(0.f, 0.f, 0.f);
         if (primS >= 0) {
@@ -127,35 +160,64 @@ PT_DEV bool shade_step(const DevScene& sc, const DevCamera& cam, const DevParams
         }
         if (flags & F_NEEOK) st.radiance += ((st.wb * Le) * st.cosA) / st.denom;
     }
-    // ---- 2. the traced path ray belongs to the next sample: retire the old path first ----
-    bool streamDone = false;
-    auto retire = [&]() {                                        // pathtracer.cu:79
-        if (!st.pixLoaded) { const float4 pix0 = *pixPtr; st.pixelColor = f3(pix0.x, pix0.y, pix0.z); st.pixLoaded = true; }
-        st.pixelColor += st.radiance;
-        st.samplesLeft--;
-        st.weight = f3(1.f, 1.f, 1.f); st.radiance = f3(0.f, 0.f, 0.f);
-        st.depth = 0; st.refractCnt = 0; bRefracted = false;
-    };
-    if (flags & F_NEWPATH) retire();
+    bool cur = (flags & F_CUR) != 0;       // a current sample exists
+    bool closing = false;                  // it has just shaded its last bounce (its NEE term is in the current slot)
+    bool shCur = false, neeCur = false, pathCur = false, shA = false, neeA = false;
+    if (flags & F_PRIMARY) *hit0Ptr = hitP;                                  // the camera ray's hit, shared by every sample
+    else if (!(flags & F_PATH) && cur) { add_to_pixel(st.radiance); cur = false; }   // the current sample closed one step ago
 
-    uint32_t nflags = 0;
-    if (flags & F_PATH) {
-        const f3 rorg = st.pathO, rdir = st.pathD;
-        if (primP < 0) {
-            st.radiance += st.weight * f3(0.1f, 0.1f, 0.1f);               // CudaUtil.cuh:375-379
-            retire();
-            if (st.samplesLeft > 0) nflags = F_PATH; else streamDone = true;
+    // ---- c. up to two hits to shade: round 0 the current path's, round 1 the first hit of the next sample ----
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+        bool go;
+        int prim = -1; float t = 0.f;
+        f3 rorg(0.f, 0.f, 0.f), rdir(0.f, 0.f, 1.f);
+        if (round == 0) {
+            go = (flags & F_PATH) && !(flags & F_PRIMARY);
+            prim = __float_as_int(hitP.y); t = hitP.x; rorg = st.pathO; rdir = st.pathD;
+            if (go && prim < 0) {
+                st.radiance += st.weight * f3(0.1f, 0.1f, 0.1f);               // CudaUtil.cuh:375-379: the path left the scene
+                add_to_pixel(st.radiance);
+                cur = false; go = false;
+            }
         } else {
-            // ---- shade a PATH hit: the whole bounce except visibility ----
+            go = (!cur || closing) && st.toStart > 0;
+            if (go) {
+                if (closing) {
+                    // the closed sample waits in slot A for its shadow ray; the pixel gets it first thing next step
+                    b.radA[sid] = make_float4(st.radiance.x, st.radiance.y, st.radiance.z, st.denom);
+                    b.wbA[sid] = make_float4(st.wb.x, st.wb.y, st.wb.z, st.cosA);
+                    b.lpA[sid] = make_float4(st.lightP.x, st.lightP.y, st.lightP.z, 0.f);
+                    b.ray_o[2][sid] = make_float4(st.shO.x, st.shO.y, st.shO.z, st.shTmax);
+                    b.ray_d[2][sid] = make_float4(st.shD.x, st.shD.y, st.shD.z, 0.f);
+                    shA = true; neeA = neeCur; shCur = false; neeCur = false; closing = false;
+                }
+                prim = __float_as_int(h0.y); t = h0.x;
+                const float4 d0 = *dir0Ptr;
+                rorg = f3(cam.pos[0], cam.pos[1], cam.pos[2]); rdir = f3(d0.x, d0.y, d0.z);
+                if (prim < 0) {
+                    // the pixel looks past the scene: every remaining sample is the ambient term (no draws, no rays)
+                    do { st.radiance = f3(0.f, 0.f, 0.f); st.radiance += f3(1.f, 1.f, 1.f) * f3(0.1f, 0.1f, 0.1f); add_to_pixel(st.radiance); } while (--st.toStart > 0);
+                    cur = false; go = false;
+                } else {
+                    st.toStart--;                                            // pathtracer.cu:77-78: next sample
+                    st.weight = f3(1.f, 1.f, 1.f); st.radiance = f3(0.f, 0.f, 0.f);
+                    st.depth = 0; st.refractCnt = 0; bRefracted = false; cur = true;
+                }
+            }
+        }
+        if (go) {
+            // ---- shade a hit: the whole bounce except visibility ----
             Surf s;
-            if (triP) surf_from_rec(rec, hitP.x, rorg, rdir, s);
-            else surf_sphere(sc, primP - sc.n_tris, hitP.x, rorg, rdir, s);
+            if (prim < sc.n_tris) { SurfRec rec; load_surf(sc, prim, rec); surf_from_rec(rec, t, rorg, rdir, s); }
+            else surf_sphere(sc, prim - sc.n_tris, t, rorg, rdir, s);
             if (sqlen(s.m.emittance) > kEps) st.radiance += st.weight * s.m.emittance;   // :220-224
             const float ior = ior_of(s.m);                                          // :231
             const int lobe = lobe_of(s.m);
             const f3 wo = -rdir;
             // NEE sample (:235-245, SamplePrimitive :38-48)
-            st.rng = peek;                                  // the light index drawn above: first draw of the bounce
+            const int li = (int)(st.rng.next() % (uint32_t)Nl);
+            const float4 l0 = sc.lights[4 * li], l1 = sc.lights[4 * li + 1], l2 = sc.lights[4 * li + 2], l3 = sc.lights[4 * li + 3];
             const f3 LV0(l0.x, l0.y, l0.z), LV1(l0.w, l1.x, l1.y), LV2(l1.z, l1.w, l2.x), LN(l2.y, l2.z, l2.w);
             const float r1u = __builtin_sqrtf(st.rng.uniform());
             const float r2u = st.rng.uniform();
@@ -166,7 +228,7 @@ PT_DEV bool shade_step(const DevScene& sc, const DevCamera& cam, const DevParams
             const float ca = dot(LN, normalize(s.p - lightP));
             st.cosA = (ca < 0.f) ? 0.f : ca;
             const f3 brdfcos = lobe_eval(lobe, s.m, ior, s.fr, wo, wl);
-            const bool neeOk = !anynan(brdfcos);
+            neeCur = !anynan(brdfcos);
             st.wb = st.weight * brdfcos;
             st.lightP = lightP;
             st.denom = sqlen(s.p - lightP) * pdfLight;
@@ -196,43 +258,28 @@ PT_DEV bool shade_step(const DevScene& sc, const DevCamera& cam, const DevParams
             }
             // shadow ray: Ray(p, P - p), t_max = |P - p| + 1 (GetLightColor :152-157)
             st.shO = s.p; st.shD = wl; st.shTmax = length(toL) + 1.0f;
-            nflags = F_SHADOW | (neeOk ? F_NEEOK : 0u);
-            if (!terminate) {
-                st.pathO = nOrg; st.pathD = wi;
-                nflags |= F_PATH;
-            } else if (st.samplesLeft > 1) {
-                nflags |= F_PATH | F_NEWPATH;      // pre-launch the next sample's camera ray beside the shadow ray
-            }
+            shCur = true;
+            if (!terminate) { st.pathO = nOrg; st.pathD = wi; pathCur = true; closing = false; }
+            else { pathCur = false; closing = true; }
         }
-    } else {
-        // only a shadow ray was traced: the last path of the stream ended at the previous bounce
-        retire();
-        streamDone = true;
     }
-    if (((nflags & F_PATH) && !(nflags & F_SHADOW)) || (nflags & F_NEWPATH)) {
-        const float4 cam0 = *dir0Ptr;
-        st.pathO = f3(cam.pos[0], cam.pos[1], cam.pos[2]);
-        st.pathD = f3(cam0.x, cam0.y, cam0.z);
-    }
-    if (bRefracted) nflags |= F_REFR;
-    st.flags = nflags;
-    return streamDone;
+    st.flags = (cur ? F_CUR : 0u) | (shCur ? F_SHADOW : 0u) | (neeCur ? F_NEEOK : 0u) | (pathCur ? F_PATH : 0u) |
+               (shA ? F_SHADOWA : 0u) | (neeA ? F_NEEOKA : 0u) | (bRefracted ? F_REFR : 0u);
+    return !cur && !shA && st.toStart == 0;
 }
 
 PT_DEV void load_state(const WfBuf& b, uint32_t sid, SState& st)
 {
     const uint4 r0 = b.rng0[sid], r1 = b.rng1[sid];
     st.rng.x0 = r0.x; st.rng.x1 = r0.y; st.rng.x2 = r0.z; st.rng.x3 = r0.w; st.rng.x4 = r1.x; st.rng.d = r1.y;
-    st.samplesLeft = (int)(r1.z >> 16); st.depth = (int)((r1.z >> 8) & 0xff); st.refractCnt = (int)(r1.z & 0xff);
+    st.toStart = (int)(r1.z >> 16); st.depth = (int)((r1.z >> 8) & 0xff); st.refractCnt = (int)(r1.z & 0xff);
     st.flags = r1.w;
     const float4 wq = b.weight[sid], rq4 = b.rad[sid];
     st.weight = f3(wq.x, wq.y, wq.z); st.radiance = f3(rq4.x, rq4.y, rq4.z);
     st.cosA = wq.w; st.denom = rq4.w;
     st.pixelColor = f3(0.f, 0.f, 0.f); st.pixLoaded = false;
-    st.wb = f3(0.f, 0.f, 0.f); st.lightP = f3(0.f, 0.f, 0.f);
-    st.pathO = st.pathD = st.shO = st.shD = f3(0.f, 0.f, 0.f); st.shTmax = 0.f;
-    // rays and the pending NEE term are fetched whatever the flags say (stale values are never used):
-    // waiting for the flags first would add a level to the kernel's dependent-load chain
+    // the current sample's rays and pending NEE term are fetched whatever the flags say (stale values are
+    // never used): nearly every step has them, and waiting for the flags first only adds latency
     const float4 po = b.ray_o[0][sid], pd = b.ray_d[0][sid];
     st.pathO = f3(po.x, po.y, po.z); st.pathD = f3(pd.x, pd.y, pd.z);
     const float4 so = b.ray_o[1][sid], sd = b.ray_d[1][sid], lpq = b.lp[sid], wbq = b.wb[sid];
@@ -251,7 +298,7 @@ PT_DEV void store_state(const WfBuf& b, uint32_t slot, const SState& st)
 {
     const uint32_t nf = st.flags;
     b.rng0[slot] = make_uint4(st.rng.x0, st.rng.x1, st.rng.x2, st.rng.x3);
-    b.rng1[slot] = make_uint4(st.rng.x4, st.rng.d, ((uint32_t)st.samplesLeft << 16) | ((uint32_t)st.depth << 8) | (uint32_t)st.refractCnt, nf);
+    b.rng1[slot] = make_uint4(st.rng.x4, st.rng.d, ((uint32_t)st.toStart << 16) | ((uint32_t)st.depth << 8) | (uint32_t)st.refractCnt, nf);
     b.weight[slot] = make_float4(st.weight.x, st.weight.y, st.weight.z, st.cosA);
     b.rad[slot] = make_float4(st.radiance.x, st.radiance.y, st.radiance.z, st.denom);
     if (st.pixLoaded) b.pix[slot] = make_float4(st.pixelColor.x, st.pixelColor.y, st.pixelColor.z, 0.f);

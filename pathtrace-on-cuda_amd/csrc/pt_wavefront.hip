@@ -8,9 +8,10 @@
 //
 //   wf_trace  closest hits of all pending path rays and visibility of all pending NEE shadow
 //             rays (one queue index space): lean kernel, 8 waves/SIMD, lanes refill from the queue
-//   wf_shade  apply NEE, shade the path hit, draw the bounce's random numbers, emit the next
-//             shadow ray + path ray (or the next sample's camera ray), or retire the stream and
-//             write its per-pass mean.
+//   wf_shade  one step of every live stream (pt_stream.h): apply the NEE terms whose shadow rays are back,
+//             shade the path hit — and, when that path ends, the first hit of the next sample too
+//             (the camera ray's hit is cached) — emit the shadow and path rays, or retire the stream
+//             and write its per-pass mean.
 //
 // The traversal kernel is persistent: a wave takes ray ids from a 16-way sharded queue in
 // chunks of <= 128 and, whenever >= 16 of its lanes have finished their ray, hands them new
@@ -48,35 +49,36 @@ constexpr int kDone = (int)0x80000000;
 constexpr int kWfBudget = 256;        // least node steps a ray may take per launch (measured: 96 cost 8 % on a 2M-stream render, >= 192 is flat)
 constexpr int kSuspInts = 4 + kWfLdsStack + kWfOvfLevels;
 
-// block-aggregated append to three lists at once: one atomicAdd per list per block.
-// (One atomic per wave was the shade kernel's bottleneck: ~100k returning atomics per launch on
-// one cache line serialise at ~88 per microsecond; 1024-thread blocks keep it to ~2k per list.)
+// block-aggregated append to four lists at once (live streams + one ray queue per kind): one atomicAdd
+// per list per block.  (One atomic per wave was the shade kernel's bottleneck: ~100k returning atomics
+// per launch on one cache line serialise at ~88 per microsecond; 1024-thread blocks keep it to ~2k per list.)
 // Must be called by every thread of the block.
-constexpr int kShadeThreads = 1024;
-PT_DEV void block_append3(bool e0, bool e1, bool e2, uint32_t id, uint32_t* c0, uint32_t* c1, uint32_t* c2,
-                          uint32_t* l0, uint32_t* l1, uint32_t* l2)
+constexpr int kShadeThreads = 1024;      // 8 waves = 2 per SIMD at <= 256 VGPRs: no spills; the kernel is memory-bound and does not care between 2 and 4 waves/SIMD
+constexpr int kLists = 1 + kRayKinds;
+PT_DEV void block_append(const bool e[kLists], uint32_t id, uint32_t* const c[kLists], uint32_t* const l[kLists])
 {
     constexpr int W = kShadeThreads / 64;
-    __shared__ uint32_t s_cnt[3][W];
-    __shared__ uint32_t s_base[3];
+    __shared__ uint32_t s_cnt[kLists][W];
+    __shared__ uint32_t s_base[kLists];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = (int)(blockDim.x >> 6);
-    const unsigned long long m0 = __ballot(e0), m1 = __ballot(e1), m2 = __ballot(e2);
-    if (lane == 0) { s_cnt[0][wave] = __builtin_popcountll(m0); s_cnt[1][wave] = __builtin_popcountll(m1); s_cnt[2][wave] = __builtin_popcountll(m2); }
+    unsigned long long m[kLists];
+#pragma unroll
+    for (int k = 0; k < kLists; k++) { m[k] = __ballot(e[k]); if (lane == 0) s_cnt[k][wave] = __builtin_popcountll(m[k]); }
     __syncthreads();
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < kLists) {
         uint32_t tot = 0;
         for (int w = 0; w < nw; w++) tot += s_cnt[threadIdx.x][w];
-        uint32_t* c = threadIdx.x == 0 ? c0 : (threadIdx.x == 1 ? c1 : c2);
-        s_base[threadIdx.x] = tot ? atomicAdd(c, tot) : 0u;
+        s_base[threadIdx.x] = tot ? atomicAdd(c[threadIdx.x], tot) : 0u;
     }
     __syncthreads();
     const unsigned long long below = (1ull << lane) - 1ull;
-    uint32_t p0 = s_base[0], p1 = s_base[1], p2 = s_base[2];
-    for (int w = 0; w < wave; w++) { p0 += s_cnt[0][w]; p1 += s_cnt[1][w]; p2 += s_cnt[2][w]; }
-    if (e0) l0[p0 + (uint32_t)__builtin_popcountll(m0 & below)] = id;
-    if (e1) l1[p1 + (uint32_t)__builtin_popcountll(m1 & below)] = id;
-    if (e2) l2[p2 + (uint32_t)__builtin_popcountll(m2 & below)] = id;
+#pragma unroll
+    for (int k = 0; k < kLists; k++) {
+        uint32_t pos = s_base[k];
+        for (int w = 0; w < wave; w++) pos += s_cnt[k][w];
+        if (e[k]) l[k][pos + (uint32_t)__builtin_popcountll(m[k] & below)] = id;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -102,12 +104,15 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
             b.staging[3 * (size_t)sid + 0] = 0.f; b.staging[3 * (size_t)sid + 1] = 0.f; b.staging[3 * (size_t)sid + 2] = 0.f;
         }
     }
-    block_append3(live, live, false, sid, &b.cnt[0].nActive, &b.cnt[0].nPath, &b.cnt[0].nShadow, b.active[0], b.rq[0], b.rq[1]);
+    const bool e[kLists] = {live, live, false, false};
+    uint32_t* const c[kLists] = {&b.cnt[0].nActive, &b.cnt[0].nRays[0][0], &b.cnt[0].nRays[1][0], &b.cnt[0].nRays[2][0]};
+    uint32_t* const l[kLists] = {b.active[0], b.rq[0], b.rq[1], b.rq[2]};
+    block_append(e, sid, c, l);
 }
 
 // ---------------------------------------------------------------------------------------
 // wf_trace: persistent closest-hit kernel with lane refill.
-// Shadow rays (queue indices >= nPath): the ray only decides whether the closest hit is the sampled light point
+// Shadow rays (kinds 1 and 2, queue indices >= nPath): the ray only decides whether the closest hit is the sampled light point
 // (GetLightColor, CudaUtil.cuh:150-166: visible iff |hit.p - P| < EPS, with t_max = |P-p|+1).
 // Any hit at t < (t_max - 1) - 5e-4 proves the closest hit is at least ~4e-4 in front of P,
 // hence not within EPS = 1e-4 of it, so traversal may stop there; what is reported is then
@@ -124,9 +129,10 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
     unsigned long long stTExh = 0;
     unsigned long long stNodeTrips = 0, stNodeLanes = 0, stTriTrips = 0, stTriLanes = 0, stRefills = 0, stRefillLanes = 0, stNoRayLanes = 0, stRays = 0;
     __shared__ int lds_stack[4][kWfLdsStack * 64];
-    // one queue index space: [0, nPath) are path rays, [nPath, nPath + nShadow) shadow rays
-    const uint32_t nPath = b.cnt[slot].nPath;
-    const uint32_t n = nPath + b.cnt[slot].nShadow;
+    // one queue index space: [0, nPath) path rays, then the shadow rays of kind 1, then those of kind 2
+    const uint32_t nPath = b.cnt[slot].nRays[0][0];
+    const uint32_t nKind1 = nPath + b.cnt[slot].nRays[1][0];
+    const uint32_t n = nKind1 + b.cnt[slot].nRays[2][0];
     if ((uint32_t)blockIdx.x * 256u >= n) return;      // surplus blocks leave before touching the queue
 
     const int lane = threadIdx.x & 63;
@@ -155,7 +161,8 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
     float bestT = 0.f, cscale = 0.f, stopBelow = 0.f;
     int bestPrim = -1, cur = kDone, sp = 0, steps = 0;
     int pend = 0;        // a leaf this ray has reached but not yet tested (0 = none): see "postponed leaves" below
-    bool degenerate = false, shadow = false;
+    bool degenerate = false;
+    int kind = 0;        // 0 path, 1/2 shadow (pt_stream.h)
 
     for (;;) {
         // ---- hand new rays to idle lanes (ballot + mbcnt compaction) ----
@@ -190,9 +197,10 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     const uint32_t r = (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
                     if (r < take) {
                         const uint32_t q = chunkPos + r;
-                        shadow = q >= nPath;
-                        sid = shadow ? b.rq[1][q - nPath] : b.rq[0][q];
-                        const float4 o = (shadow ? b.ray_o[1] : b.ray_o[0])[sid], d = (shadow ? b.ray_d[1] : b.ray_d[0])[sid];
+                        kind = q < nPath ? 0 : (q < nKind1 ? 1 : 2);
+                        sid = kind == 0 ? b.rq[0][q] : (kind == 1 ? b.rq[1][q - nPath] : b.rq[2][q - nKind1]);
+                        const float4 o = (kind == 0 ? b.ray_o[0] : (kind == 1 ? b.ray_o[1] : b.ray_o[2]))[sid];
+                        const float4 d = (kind == 0 ? b.ray_d[0] : (kind == 1 ? b.ray_d[1] : b.ray_d[2]))[sid];
                         org = f3(o.x, o.y, o.z); dir = f3(d.x, d.y, d.z);
                         inv = f3(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);                     // inv(), CudaUtil.cuh:60-63
                         const float L = __builtin_sqrtf(inv.x * inv.x + inv.y * inv.y + inv.z * inv.z);
@@ -206,9 +214,9 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                             inv.z = (__builtin_fabsf(inv.z) <= 1e30f) ? inv.z : __builtin_copysignf(1e30f, dir.z);
                             cscale = 1.0000019f;
                         }
-                        stopBelow = shadow ? (o.w - 1.0f) - 5e-4f : -__builtin_inff();
+                        stopBelow = kind != 0 ? (o.w - 1.0f) - 5e-4f : -__builtin_inff();
                         steps = 0;
-                        const float2 prev = (shadow ? b.hit[1] : b.hit[0])[sid];
+                        const float2 prev = (kind == 0 ? b.hit[0] : (kind == 1 ? b.hit[1] : b.hit[2]))[sid];
                         const int pp = __float_as_int(prev.y);
                         if (pp <= -2) {
                             // resume a suspended traversal
@@ -245,7 +253,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                         if (pend != 0) { if (sp < kWfLdsStack) stack[sp * 64] = pend; else ovf[(sp - kWfLdsStack) * ovfStride] = pend; sp++; pend = 0; }
                         r[0] = cur; r[1] = sp; r[2] = __float_as_int(bestT); r[3] = bestPrim;
                         for (int k = 0; k < sp; k++) r[4 + k] = (k < kWfLdsStack) ? stack[k * 64] : ovf[(k - kWfLdsStack) * ovfStride];
-                        (shadow ? b.hit[1] : b.hit[0])[sid] = make_float2(bestT, __int_as_float(-2 - (int)rec));
+                        (kind == 0 ? b.hit[0] : (kind == 1 ? b.hit[1] : b.hit[2]))[sid] = make_float2(bestT, __int_as_float(-2 - (int)rec));
                         hasRay = false;
                         cur = kDone;
                     } else {
@@ -357,7 +365,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     float root;
                     if (sphere_root(f3(c.x, c.y, c.z), c.w, org, dir, bestT, root)) { bestT = root; bestPrim = sc.n_tris + s; }
                 }
-                (shadow ? b.hit[1] : b.hit[0])[sid] = make_float2(bestT, __int_as_float(bestPrim));
+                (kind == 0 ? b.hit[0] : (kind == 1 ? b.hit[1] : b.hit[2]))[sid] = make_float2(bestT, __int_as_float(bestPrim));
                 hasRay = false;
                 if (STAT) stRays++;
             }
@@ -380,7 +388,8 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
 // ---------------------------------------------------------------------------------------
 // wf_shade: one thread per live stream, one bounce.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kShadeThreads, 4)
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 256, WAVES)
 void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, int slotOut, int slotClear, int listIn)
 {
     const uint32_t nIn = b.cnt[slotIn].nActive;
@@ -388,32 +397,34 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
     if ((uint32_t)blockIdx.x * blockDim.x >= nIn) return;
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const bool have = idx < nIn;
-    bool emitPath = false, emitShadow = false, alive = false;
+    bool alive = false, emit[kRayKinds] = {false, false, false};
     uint32_t sid = 0;
     if (have) {
         sid = b.active[listIn][idx];
         SState st;
-        const float2 hitP = b.hit[0][sid], hitS = b.hit[1][sid];      // same fetch level as the state
+        const float2 hitP = b.hit[0][sid], hitS = b.hit[1][sid], hitA = b.hit[2][sid];      // same fetch level as the state
         load_state(b, sid, st);
         // a ray of this stream is still being traversed (time-sliced): wait one iteration
         const int pendP = (st.flags & F_PATH) ? __float_as_int(hitP.y) : -1, pendS = (st.flags & F_SHADOW) ? __float_as_int(hitS.y) : -1;
-        if (pendP <= -2 || pendS <= -2) {
-            alive = true; emitPath = pendP <= -2; emitShadow = pendS <= -2;
+        const int pendA = (st.flags & F_SHADOWA) ? __float_as_int(hitA.y) : -1;
+        if (pendP <= -2 || pendS <= -2 || pendA <= -2) {
+            alive = true; emit[0] = pendP <= -2; emit[1] = pendS <= -2; emit[2] = pendA <= -2;
         } else {
-            const bool done = shade_step(sc, cam, prm, st, hitP, hitS, &b.pix[sid], &b.dir0[sid]);
+            const bool done = shade_step(sc, cam, prm, b, sid, st, hitP, hitS, hitA);
             if (done) {
                 write_mean(b, prm, sid, st);
             } else {
                 const uint32_t nf = st.flags;
                 store_state(b, sid, st);
                 alive = true;
-                emitPath = (nf & F_PATH) != 0;
-                emitShadow = (nf & F_SHADOW) != 0;
+                emit[0] = (nf & F_PATH) != 0; emit[1] = (nf & F_SHADOW) != 0; emit[2] = (nf & F_SHADOWA) != 0;
             }
         }
     }
-    block_append3(alive, emitPath, emitShadow, sid, &b.cnt[slotOut].nActive, &b.cnt[slotOut].nPath, &b.cnt[slotOut].nShadow,
-                  b.active[listIn ^ 1], b.rq[0], b.rq[1]);
+    const bool e[kLists] = {alive, emit[0], emit[1], emit[2]};
+    uint32_t* const c[kLists] = {&b.cnt[slotOut].nActive, &b.cnt[slotOut].nRays[0][0], &b.cnt[slotOut].nRays[1][0], &b.cnt[slotOut].nRays[2][0]};
+    uint32_t* const l[kLists] = {b.active[listIn ^ 1], b.rq[0], b.rq[1], b.rq[2]};
+    block_append(e, sid, c, l);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -437,11 +448,15 @@ void wf_drain(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
     SState st;
     load_state(b, sid, st);
     for (;;) {
-        float2 hitP = make_float2(0.f, __int_as_float(-1)), hitS = make_float2(0.f, __int_as_float(-1));
+        float2 hitP = make_float2(0.f, __int_as_float(-1)), hitS = hitP, hitA = hitP;
         TraceStats ts{0, 0, 0};
+        if (st.flags & F_SHADOWA) {
+            const float4 ao = b.ray_o[2][sid], ad = b.ray_d[2][sid];
+            float t; const int prim = trace_closest<false>(sc, f3(ao.x, ao.y, ao.z), f3(ad.x, ad.y, ad.z), ao.w, stack, t, ts); hitA = make_float2(t, __int_as_float(prim));
+        }
         if (st.flags & F_SHADOW) { float t; const int prim = trace_closest<false>(sc, st.shO, st.shD, st.shTmax, stack, t, ts); hitS = make_float2(t, __int_as_float(prim)); }
         if (st.flags & F_PATH) { float t; const int prim = trace_closest<false>(sc, st.pathO, st.pathD, 999999.f, stack, t, ts); hitP = make_float2(t, __int_as_float(prim)); }
-        if (shade_step(sc, cam, prm, st, hitP, hitS, &b.pix[sid], &b.dir0[sid])) break;
+        if (shade_step(sc, cam, prm, b, sid, st, hitP, hitS, hitA)) break;
     }
     write_mean(b, prm, sid, st);
 }
@@ -458,10 +473,10 @@ static size_t cohort_bytes(size_t nStreams, int traceBlocks)
 {
     const size_t n16 = (nStreams + 3) & ~(size_t)3;
     size_t b = 0;
-    b += n16 * 16 * 8;          // 8 state arrays
-    b += n16 * 16 * 4;          // ray_o/ray_d x2
-    b += n16 * 8 * 2;           // hits
-    b += n16 * 4 * 4;           // active x2, rq x2
+    b += n16 * 16 * 11;                       // 11 float4 state arrays
+    b += n16 * 16 * 2 * ptd::kRayKinds;       // ray_o/ray_d per kind
+    b += n16 * 8 * (ptd::kRayKinds + 1);      // hits per kind + the cached camera-ray hit
+    b += n16 * 4 * (2 + ptd::kRayKinds);      // active x2, one ray queue per kind
     b += 3 * ptd::kWfSlotBytes; // counters
     b += (size_t)traceBlocks * 256 * ptd::kWfOvfLevels * 4;
     b += 2 * ((nStreams / 4 + 1024) * ptd::kSuspInts * 4 + 16);
@@ -498,10 +513,12 @@ static void carve(char* p, size_t nStreams, int traceBlocks, ptd::WfBuf& b)
     b.rng0 = (uint4*)take(n16 * 16); b.rng1 = (uint4*)take(n16 * 16);
     b.weight = (float4*)take(n16 * 16); b.rad = (float4*)take(n16 * 16); b.pix = (float4*)take(n16 * 16);
     b.dir0 = (float4*)take(n16 * 16); b.wb = (float4*)take(n16 * 16); b.lp = (float4*)take(n16 * 16);
-    for (int k = 0; k < 2; k++) { b.ray_o[k] = (float4*)take(n16 * 16); b.ray_d[k] = (float4*)take(n16 * 16); }
-    for (int k = 0; k < 2; k++) b.hit[k] = (float2*)take(n16 * 8);
+    b.radA = (float4*)take(n16 * 16); b.wbA = (float4*)take(n16 * 16); b.lpA = (float4*)take(n16 * 16);
+    for (int k = 0; k < ptd::kRayKinds; k++) { b.ray_o[k] = (float4*)take(n16 * 16); b.ray_d[k] = (float4*)take(n16 * 16); }
+    for (int k = 0; k < ptd::kRayKinds; k++) b.hit[k] = (float2*)take(n16 * 8);
+    b.hit0 = (float2*)take(n16 * 8);
     for (int k = 0; k < 2; k++) b.active[k] = (uint32_t*)take(n16 * 4);
-    for (int k = 0; k < 2; k++) b.rq[k] = (uint32_t*)take(n16 * 4);
+    for (int k = 0; k < ptd::kRayKinds; k++) b.rq[k] = (uint32_t*)take(n16 * 4);
     b.cnt = (ptd::WfCounters*)take(3 * ptd::kWfSlotBytes);
     b.ovf = (int*)take((size_t)traceBlocks * 256 * ptd::kWfOvfLevels * 4);
     b.suspCap = (uint32_t)(nStreams / 4 + 1024);
@@ -540,7 +557,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     static const int guideShift = getenv("PTAMD_GS") ? atoi(getenv("PTAMD_GS")) : 9;
     static const int budgetShift = getenv("PTAMD_BS") ? atoi(getenv("PTAMD_BS")) : 14;
     static const int budgetMin = getenv("PTAMD_BM") ? atoi(getenv("PTAMD_BM")) : kWfBudget;
-    static const int shadeThreads = getenv("PTAMD_ST") ? atoi(getenv("PTAMD_ST")) : kShadeThreads;
+    static const int shadeWaves = getenv("PTAMD_SW") ? atoi(getenv("PTAMD_SW")) : 3;
     static const int triTrig = getenv("PTAMD_TT") ? atoi(getenv("PTAMD_TT")) : 64;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
     unsigned long long* const traceStat = g_traceStat;
@@ -557,7 +574,9 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             if (traceStat) hipLaunchKernelGGL(wf_trace<true>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, traceStat, it < 2700 ? it : 2699);
             else hipLaunchKernelGGL(wf_trace<false>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, (unsigned long long*)nullptr, 0);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
-            hipLaunchKernelGGL(wf_shade, dim3((liveBound + shadeThreads - 1) / shadeThreads), dim3(shadeThreads), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
+            if (shadeWaves == 2) hipLaunchKernelGGL(wf_shade<2>, dim3((liveBound + 511) / 512), dim3(512), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
+            else if (shadeWaves == 3) hipLaunchKernelGGL(wf_shade<3>, dim3((liveBound + 767) / 768), dim3(768), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
+            else hipLaunchKernelGGL(wf_shade<4>, dim3((liveBound + 1023) / 1024), dim3(1024), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(h_cnt, &b.cnt[it % 3].nActive, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
