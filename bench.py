@@ -17,12 +17,13 @@ ONE collective (RCCL over xGMI) and de-interleaved — that exchange is inside t
 region.  value = W*H*spp_per_pass*K / seconds / 1e6, whole job, inputs resident in HBM.
 
 Also on the JSON line:
-  roofline     — for the dominant kernel (render_units): achieved = algorithmic bytes per
-                 launch / average launch duration (HIP events on the launch stream), against
-                 the 8 TB/s HBM peak.  Algorithmic bytes per sample are those of the
-                 REFERENCE's traversal (40 B per node fetched + 36 B per
-                 triangle test + 156 B per ray with an accepted hit, + 24 B/spp_per_pass),
-                 counted by the instrumented CPU oracle on this same scene.
+  roofline     — for the dominant kernel (wf_trace, the traversal kernel of the pipeline):
+                 achieved = algorithmic bytes per launch / average launch duration (HIP event
+                 pairs on the launch stream around every launch), against the 8 TB/s HBM peak;
+                 the GPU's measured streaming rate (float4 triad) is reported beside it.
+                 Algorithmic bytes per sample are those of the REFERENCE's traversal (SURVEY.md
+                 §8d: 40 B per node fetched + 36 B per triangle test), counted by the
+                 instrumented CPU oracle on this same scene and frame.
   cpu_baseline — the CPU oracle (restatement of the reference's algorithm) timed on this
                  host's cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -192,8 +193,12 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        try:
+            triad = ptamd.triad_gbps(1 << 30, 10, dev.index or 0)       # this GPU's measured streaming rate
+        except Exception:
+            triad = None
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "peak_measured_triad": triad,
                            "kernel": "wf_trace", "kernel_ms_avg": k_ms, "kernel_ms_max": t_max_ms, "launches_timed": int(t_launches),
                            "kernel_ms_sum": t_sum_ms, "samples_per_launch": units_per_launch,
                            "algorithmic_bytes_per_sample": bps_trav,
@@ -201,8 +206,9 @@ def main():
                            "bounce_iterations": int(scene.last_iterations()),
                            "pipeline_ms_per_step": (float(np.sum(kern_ms)) / args.steps) if len(kern_ms) else None,
                            "note": "algorithmic bytes are those of the REFERENCE traversal (brute force on degenerate rays); this kernel's "
-                                   "own fetches are ~8x fewer and mostly cache hits, so frac > 1 means faster than a bandwidth-perfect "
-                                   "execution of the reference's traversal, not a saturated HBM (DESIGN.md section 5)"}
+                                   "own fetches are far fewer (a 4-wide quantised tree, camera rays traced once per pass) and mostly cache "
+                                   "hits, so frac > 1 means faster than a bandwidth-perfect execution of the reference's traversal, not a "
+                                   "saturated HBM; the kernel is VALU-issue bound (DESIGN.md section 5)"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         # a cheap sanity guard on the timed output (not a parity test): finite, plausible brightness

@@ -205,6 +205,9 @@ PT_API int  pt_dbg_raycast(PtScene* s, const float* rays8, int32_t n, float* out
 PT_API int  pt_dbg_bxdf(int32_t device, int32_t lobe, const float* in28, int32_t n, float* out12);
 PT_API int  pt_dbg_rng(int32_t device, uint64_t seed, int32_t n, uint32_t* raw_out, float* uniform_out);
 PT_API int  pt_dbg_math(int32_t device, const float* in, int32_t n, float* out8);
+/* Measurement aid: stream triad a = b + s*c over three float4 arrays of `bytes_per_array`
+ * each, `iters` times; *gb_per_s = bytes moved (2 reads + 1 write per element) / time of the timed launches. */
+PT_API int  pt_dbg_triad(int32_t device, int64_t bytes_per_array, int32_t iters, double* gb_per_s);
 /* Work counters of the last pt_render_tiles on this scene (int64 x 8):
  * [0] rays [1] node records fetched [2] triangle tests [3] sphere tests [4] rays with hit
  * [5] camera paths [6] loop trips of the wave scheduler [7] lane-trips with an active ray */

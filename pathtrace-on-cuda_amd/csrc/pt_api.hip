@@ -488,6 +488,45 @@ int pt_dbg_rng(int32_t device, uint64_t seed, int32_t n, uint32_t* raw_out, floa
     return with_buffers(device, nullptr, 0, raw_out, (size_t)n * 4, uniform_out, (size_t)n * 4,
                         [&](void*, void* o, void* o2) { return ptk_dbg_rng(seed, n, (uint32_t*)o, (float*)o2, nullptr); });
 }
+__global__ __launch_bounds__(256) void triad_kernel(float4* __restrict__ a, const float4* __restrict__ b, const float4* __restrict__ c, float s, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const float4 x = b[i], y = c[i];
+        a[i] = make_float4(x.x + s * y.x, x.y + s * y.y, x.z + s * y.z, x.w + s * y.w);
+    }
+}
+
+int pt_dbg_triad(int32_t device, int64_t bytes_per_array, int32_t iters, double* gb_per_s)
+{
+    if (!gb_per_s || bytes_per_array < 4096 || iters < 1) { pt_set_error("pt_dbg_triad: bad argument"); return PT_ERR_INVALID; }
+    HIPCHK(hipSetDevice(device));
+    const size_t n = (size_t)bytes_per_array / 16;
+    float4 *a = nullptr, *b = nullptr, *c = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = PT_OK;
+    do {
+        if (hipMalloc((void**)&a, n * 16) != hipSuccess || hipMalloc((void**)&b, n * 16) != hipSuccess || hipMalloc((void**)&c, n * 16) != hipSuccess) { pt_set_error("pt_dbg_triad: out of device memory"); rc = PT_ERR_DEVICE; break; }
+        (void)hipMemset(b, 0, n * 16); (void)hipMemset(c, 0, n * 16);
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        const unsigned blocks = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(triad_kernel, dim3(blocks), dim3(256), 0, 0, a, b, c, 0.5f, n);       // warm-up
+        (void)hipEventRecord(e0, 0);
+        for (int k = 0; k < iters; k++) hipLaunchKernelGGL(triad_kernel, dim3(blocks), dim3(256), 0, 0, a, b, c, 0.5f, n);
+        (void)hipEventRecord(e1, 0);
+        if (hipEventSynchronize(e1) != hipSuccess) { pt_set_error("pt_dbg_triad: kernel failed"); rc = PT_ERR_DEVICE; break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *gb_per_s = 3.0 * (double)n * 16.0 * iters / ((double)ms * 1e-3) / 1e9;
+    } while (0);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (c) (void)hipFree(c);
+    return rc;
+}
+
 int pt_dbg_math(int32_t device, const float* in, int32_t n, float* out8)
 {
     if (!in || !out8 || n < 0) { pt_set_error("pt_dbg_math: bad argument"); return PT_ERR_INVALID; }

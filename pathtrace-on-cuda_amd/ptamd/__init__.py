@@ -76,6 +76,7 @@ API = [
     ("pt_dbg_bxdf", C.c_int, [C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     ("pt_dbg_rng", C.c_int, [C.c_int32, C.c_uint64, C.c_int32, _P, _P]),
     ("pt_dbg_math", C.c_int, [C.c_int32, _P, C.c_int32, _P]),
+    ("pt_dbg_triad", C.c_int, [C.c_int32, C.c_int64, C.c_int32, _P]),
     ("pt_last_counters", C.c_int, [_P, _P]),
     ("pt_dbg_trace_timeline", C.c_int, [_P, _P, C.c_int32]),
     ("pt_enable_counters", C.c_int, [_P, C.c_int32]),
@@ -331,6 +332,13 @@ def dbg_rng(seed, n, device=0):
     uni = np.zeros(n, np.float32)
     _check(lib().pt_dbg_rng(device, seed, n, _ptr(raw), _ptr(uni)), "pt_dbg_rng")
     return raw, uni
+
+
+def triad_gbps(bytes_per_array=1 << 30, iters=10, device=0):
+    """Measured streaming bandwidth of this GPU (float4 triad, 2 reads + 1 write), GB/s."""
+    out = C.c_double(0.0)
+    _check(lib().pt_dbg_triad(int(device), int(bytes_per_array), int(iters), C.byref(out)), "pt_dbg_triad")
+    return float(out.value)
 
 
 def dbg_math(x, device=0):
