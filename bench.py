@@ -185,12 +185,16 @@ def main():
             k_ms = float(np.sum(kern_ms)); units_per_launch = call_samples; t_launches = int(len(kern_ms))
             achieved = units_per_launch * bps_all / (k_ms * 1e-3) / 1e9
         traffic = None
+        traffic_spp = None
         tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
-                if tj.get("spp_per_pass") == args.spp and tj.get("n_gpus", 1) == world and tj.get("steps") == args.steps:
+                # per-launch traffic of the same K-pass call (same streams in flight per launch); the PMC passes may have been
+                # collected at a smaller spp_per_pass (fewer launches of the same kind) — the file says which
+                if tj.get("n_gpus", 1) == world and tj.get("steps") == args.steps:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_spp = tj.get("spp_per_pass")
             except Exception:
                 traffic = None
         try:
@@ -198,7 +202,7 @@ def main():
         except Exception:
             triad = None
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "peak_measured_triad": triad,
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_pmc_spp_per_pass": traffic_spp, "peak_measured_triad": triad,
                            "kernel": "wf_trace", "kernel_ms_avg": k_ms, "kernel_ms_max": t_max_ms, "launches_timed": int(t_launches),
                            "kernel_ms_sum": t_sum_ms, "samples_per_launch": units_per_launch,
                            "algorithmic_bytes_per_sample": bps_trav,

@@ -122,7 +122,7 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
 // STAT: a diagnostic build that also counts trips and the lanes they serve (pt_last_counters; PTAMD_TSTAT=1).
 template <bool STAT>
 __global__ __launch_bounds__(256, 8)
-void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift, int triTrig,
+void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift, int triTrig, int refillMin,
               unsigned long long* stat, int statLaunch)
 {
     const unsigned long long stT0 = STAT ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz
@@ -168,7 +168,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
         // ---- hand new rays to idle lanes (ballot + mbcnt compaction) ----
         const unsigned long long idle = __ballot(!hasRay);
         const int nIdle = __builtin_popcountll(idle);
-        if (!exhausted && (nIdle >= kWfRefill)) {
+        if (!exhausted && (nIdle >= refillMin)) {
             if (chunkPos == chunkEnd) {
                 // The queue index space is cut into kWfShards ranges, each with its own head word (a
                 // single word saturates near 88 returning atomics per microsecond, which throttled
@@ -558,6 +558,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     static const int budgetShift = getenv("PTAMD_BS") ? atoi(getenv("PTAMD_BS")) : 14;
     static const int budgetMin = getenv("PTAMD_BM") ? atoi(getenv("PTAMD_BM")) : kWfBudget;
     static const int shadeWaves = getenv("PTAMD_SW") ? atoi(getenv("PTAMD_SW")) : 3;
+    static const int refillMin = getenv("PTAMD_RF") ? atoi(getenv("PTAMD_RF")) : kWfRefill;     // idle lanes that trigger a refill
     static const int triTrig = getenv("PTAMD_TT") ? atoi(getenv("PTAMD_TT")) : 64;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
     unsigned long long* const traceStat = g_traceStat;
@@ -571,8 +572,8 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
             const bool timed = trace_ev && it < trace_ev_pairs;
             if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
-            if (traceStat) hipLaunchKernelGGL(wf_trace<true>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, traceStat, it < 2700 ? it : 2699);
-            else hipLaunchKernelGGL(wf_trace<false>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, (unsigned long long*)nullptr, 0);
+            if (traceStat) hipLaunchKernelGGL(wf_trace<true>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, traceStat, it < 2700 ? it : 2699);
+            else hipLaunchKernelGGL(wf_trace<false>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, (unsigned long long*)nullptr, 0);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
             if (shadeWaves == 2) hipLaunchKernelGGL(wf_shade<2>, dim3((liveBound + 511) / 512), dim3(512), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
             else if (shadeWaves == 3) hipLaunchKernelGGL(wf_shade<3>, dim3((liveBound + 767) / 768), dim3(768), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);

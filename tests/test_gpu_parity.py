@@ -322,3 +322,27 @@ def test_tiny_scenes_single_leaf_tree():
         for mode in (1, 0):
             sc.set_mode(mode)
             _check_image(sc.render(ptamd.make_camera(W, H), ptamd.default_params(passes=2, spp_per_pass=4)), img_o, f"{len(prims)} tris mode {mode}")
+
+
+@pytest.mark.parametrize("max_bounce,rr_bounce,spp,passes", [(1, 3, 1, 1), (1, 3, 7, 2), (2, 0, 5, 2), (3, 1, 6, 1), (8, 3, 1, 3)])
+def test_short_paths_and_single_samples(max_bounce, rr_bounce, spp, passes):
+    """The stream step overlaps consecutive samples (the next sample's first bounce is shaded in the step that ends
+    a path).  Its corner cases: paths that end at their very first bounce (max_bounce 1: every step closes one
+    sample and opens another), roulette from bounce 0, a single sample per pass, pixels that see only background
+    — with analytic spheres (refraction chains) in the frame, in both render modes."""
+    prims = ptamd.gen_scene(1, 16)
+    nodes, tris, _ = ptamd.build_bvh(prims)
+    sph = make_test_spheres()
+    W, H = 96, 40
+    img_o, _ = O.Scene(nodes.tobytes(), tris, sph).render(
+        O.make_camera(W, H), O.make_params(W, H, passes, spp, max_bounce=max_bounce, rr_bounce=rr_bounce), 4)
+    sc = ptamd.Scene(nodes, tris, sph)
+    for mode in (1, 0):
+        sc.set_mode(mode)
+        img = sc.render(ptamd.make_camera(W, H), ptamd.default_params(passes=passes, spp_per_pass=spp, max_bounce=max_bounce, rr_bounce=rr_bounce))
+        _check_image(img, img_o, f"max_bounce {max_bounce} rr {rr_bounce} spp {spp} mode {mode}")
+
+
+def test_stream_triad_measures_a_plausible_bandwidth():
+    gbps = ptamd.triad_gbps(1 << 28, 5)
+    assert 500.0 < gbps < 9000.0, gbps

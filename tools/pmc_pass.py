@@ -20,12 +20,25 @@ def main():
         d = tempfile.mkdtemp(prefix="pmc%d_" % i, dir="/tmp")
         t0 = time.time()
         print("set %d %s ..." % (i, cs), flush=True)
-        try:
-            r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + cs + ["--output-format", "csv", "-d", d, "--"] + cmd,
-                               env=env, cwd=os.getcwd(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=per_set_timeout)
-        except subprocess.TimeoutExpired:
+        logf = open(os.path.join(d, "stdout.log"), "w")
+        proc = subprocess.Popen(["rocprofv3", "--kernel-trace", "--pmc"] + cs + ["--output-format", "csv", "-d", d, "--"] + cmd,
+                                env=env, cwd=os.getcwd(), stdout=logf, stderr=subprocess.STDOUT, text=True)
+        timed_out = False
+        while proc.poll() is None:
+            time.sleep(5)
+            el = time.time() - t0
+            if int(el) % 60 < 5:
+                print("   ... %d s" % el, flush=True)          # heartbeat: a silent GPU command is taken to be hung
+            if el > per_set_timeout:
+                proc.kill(); proc.wait(); timed_out = True
+                break
+        logf.close()
+        if timed_out:
             print("set %d TIMED OUT after %d s: stopping (no further GPU step after a timeout)" % (i, per_set_timeout), flush=True)
             break
+
+        class R: pass
+        r = R(); r.returncode = proc.returncode; r.stdout = open(os.path.join(d, "stdout.log")).read()
         print("   %.1f s" % (time.time() - t0), flush=True)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         print("set %d %s rc=%d files=%d" % (i, cs, r.returncode, len(files)), flush=True)
