@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """Turn the raw per-kernel sums of tools/pmc_pass.py (counter sets tools/pmc_sets/traffic.txt) into the summary
-bench.py reads for roofline.traffic:   python3 tools/pmc_traffic.py RAW.json OUT.json --spp 256 --steps 8
-HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / launches: rocprofv3 reports both in KiB, and on gfx950
-FETCH_SIZE tallies 128-byte requests at 64 bytes (MI355X_MICROARCH.md, HBM section), so it is doubled.  That
-correction is calibrated for wide coalesced loads; for the scattered 16-byte-per-lane fetches of the traversal kernel
-it is an upper bound on the read traffic."""
+bench.py reads for roofline.traffic:   python3 tools/pmc_traffic.py RAW.json OUT.json --spp 64 --steps 8
+HBM-side bytes per launch are computed from the L2's fabric request counters, the way rocprofv3 derives
+FETCH_SIZE / WRITE_SIZE, but with the request sizes counted exactly:
+  read  = 32 B x RDREQ_32B + 128 B x RDREQ_128B + 64 B x (RDREQ - RDREQ_32B - RDREQ_128B)
+  write = 64 B x WRREQ_64B + 32 B x (WRREQ - WRREQ_64B)
+(MI355X_MICROARCH.md, HBM section: FETCH_SIZE tallies 128-byte requests at 64 bytes on gfx950 and has to be doubled
+for wide loads; counting the 128-byte requests separately makes the correction exact instead).  Infinity-Cache hits
+are included in these counters, so this is an upper bound on DRAM traffic."""
 import argparse, json
 ap = argparse.ArgumentParser()
 ap.add_argument("raw"); ap.add_argument("out"); ap.add_argument("--spp", type=int, default=256); ap.add_argument("--steps", type=int, default=8)
@@ -13,12 +16,16 @@ raw = json.load(open(a.raw))
 res = {"command": "python3 tools/pmc_pass.py RAW tools/pmc_sets/traffic.txt -- " + raw["command"] + "   (separate --pmc passes, --kernel-trace only)",
        "spp_per_pass": a.spp, "n_gpus": 1, "steps": a.steps, "kernels": {}}
 for name, c in raw["kernels"].items():
-    if "launches" not in c or "FETCH_SIZE" not in c:
+    if "launches" not in c or "TCC_EA0_RDREQ_sum" not in c:
         continue
     k = dict(c)
     n = c["launches"]
-    k["hbm_bytes_per_launch_uncorrected"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / n
-    k["hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / n
+    rd, rd32, rd128 = c["TCC_EA0_RDREQ_sum"], c.get("TCC_EA0_RDREQ_32B_sum", 0.0), c.get("TCC_EA0_RDREQ_128B_sum", 0.0)
+    wr, wr64 = c["TCC_EA0_WRREQ_sum"], c.get("TCC_EA0_WRREQ_64B_sum", 0.0)
+    k["read_bytes_per_launch"] = (32.0 * rd32 + 128.0 * rd128 + 64.0 * (rd - rd32 - rd128)) / n
+    k["write_bytes_per_launch"] = (64.0 * wr64 + 32.0 * (wr - wr64)) / n
+    k["hbm_bytes_per_launch"] = k["read_bytes_per_launch"] + k["write_bytes_per_launch"]
+    k["fetch_size_equivalent_bytes_per_launch"] = (32.0 * rd32 + 64.0 * (rd - rd32)) / n      # what FETCH_SIZE would report
     if c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0) > 0:
         k["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     if c.get("SQ_ACTIVE_INST_VALU"):
