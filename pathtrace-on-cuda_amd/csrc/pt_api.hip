@@ -30,6 +30,7 @@ size_t ptk_wf_work_bytes(size_t nUnits, int traceBlocks);
 int ptk_wf_cohorts(size_t nUnits);
 const float* ptk_wf_staging(void* work);
 void ptk_wf_set_stat(void*);
+int ptk_wf_stack_capacity(void);
 hipError_t ptk_wf_render(int, const ptd::DevScene*, const ptd::DevCamera*, const ptd::DevParams*, void*, int, uint32_t*, hipStream_t, hipStream_t*,
                          hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t*, int*, hipEvent_t*, int, int*, int);
 }
@@ -163,6 +164,11 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     pt_build_accel(nodes, n_nodes, tris, n_tris, accel);
     if (accel.depth > ptd::kStackDepth) {
         pt_set_error("pt_scene_create: traversal tree depth %d exceeds the traversal stack (%d)", accel.depth, ptd::kStackDepth);
+        return PT_ERR_UNSUPPORTED;
+    }
+    if (3 * accel.quad_depth + 2 > ptk_wf_stack_capacity()) {
+        pt_set_error("pt_scene_create: 4-wide traversal tree depth %d needs more than the %d stack entries of the traversal kernel",
+                     accel.quad_depth, ptk_wf_stack_capacity());
         return PT_ERR_UNSUPPORTED;
     }
     max_depth = accel.depth;

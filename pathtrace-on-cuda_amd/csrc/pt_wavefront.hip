@@ -4,7 +4,7 @@
 // ~11 % SIMD lane utilisation (profiles/r01_pmc_megakernel_v1.json): rays of very different
 // length share a wave, leaf code runs for a few lanes at a time, and the fat shading code
 // holds 190 VGPRs (2 waves/SIMD).  Here every (pixel, pass) is a *stream* whose state lives
-// in HBM as SoA float4 arrays; each iteration advances every live stream by one bounce:
+// in HBM as SoA float4 arrays; each iteration advances every live stream by one step:
 //
 //   wf_trace  closest hits of all pending path rays and visibility of all pending NEE shadow
 //             rays (one queue index space): lean kernel, 8 waves/SIMD, lanes refill from the queue
@@ -14,10 +14,11 @@
 //             and write its per-pass mean.
 //
 // The traversal kernel is persistent: a wave takes ray ids from a 16-way sharded queue in
-// chunks of <= 128 and, whenever >= 16 of its lanes have finished their ray, hands them new
+// chunks of <= 128 and, whenever >= 24 of its lanes have finished their ray, hands them new
 // ones (ballot + prefix-popcount compaction), so lanes do not idle for the longest ray of the
-// wave.  Each trip of its loop the wave votes between a node step and a triangle test, so only
-// one code path runs and it serves the majority.  Rays that exceed a node budget are suspended
+// wave.  It walks the 4-wide quantised tree (pt_device.h).  Each trip of its loop the wave runs
+// ONE of two code paths, a node step or a triangle test; a ray that reaches a leaf parks it and
+// keeps walking, so both kinds of trip run fuller.  Rays that exceed a node budget are suspended
 // and resumed by the next launch (time slicing).  Shadow rays stop at the first hit that is
 // provably in front of the sampled light point (result-neutral, see wf_trace).
 //
@@ -37,7 +38,7 @@
 namespace ptd {
 
 constexpr int kWfLdsStack = 16;      // stack entries per lane kept in LDS (4 KB / wave -> 8 waves/SIMD fit)
-constexpr int kWfOvfLevels = 32;     // further levels spill to global memory (never seen on the config scenes)
+constexpr int kWfOvfLevels = 48;     // further levels spill to global memory (never needed on the config scenes: 4-wide depth 12 -> at most 38 entries)
 constexpr int kWfChunk = 128;        // most ray ids a wave takes from a queue shard per atomic (measured optimum 116-229)
 constexpr int kWfRefill = 24;        // refill lanes once this many are idle (measured: 8..16 -2 %, 32 -0.4 %)
 constexpr int kDone = (int)0x80000000;
@@ -51,9 +52,9 @@ constexpr int kSuspInts = 4 + kWfLdsStack + kWfOvfLevels;
 
 // block-aggregated append to four lists at once (live streams + one ray queue per kind): one atomicAdd
 // per list per block.  (One atomic per wave was the shade kernel's bottleneck: ~100k returning atomics
-// per launch on one cache line serialise at ~88 per microsecond; 1024-thread blocks keep it to ~2k per list.)
+// per launch on one cache line serialise at ~88 per microsecond; 768-thread blocks keep it to ~3k per list.)
 // Must be called by every thread of the block.
-constexpr int kShadeThreads = 1024;      // 8 waves = 2 per SIMD at <= 256 VGPRs: no spills; the kernel is memory-bound and does not care between 2 and 4 waves/SIMD
+constexpr int kShadeThreads = 1024;      // largest wf_shade workgroup (the default variant runs 768 = 3 waves/SIMD at 146 VGPRs, no spills)
 constexpr int kLists = 1 + kRayKinds;
 PT_DEV void block_append(const bool e[kLists], uint32_t id, uint32_t* const c[kLists], uint32_t* const l[kLists])
 {
@@ -239,11 +240,9 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
         if (__ballot(hasRay) == 0ull) { if (exhausted) break; else continue; }
 
         if (hasRay) {
-            // Each trip the wave votes: if more lanes hold an interior node than a leaf, the node
-            // lanes do one node step, otherwise the leaf lanes test ONE triangle each.  Only one
-            // code path runs per trip and it always serves the majority.  (The classic while-while
-            // shape made 64 lanes wait for the slowest lane to reach a leaf every round — 24 % VALU
-            // lane utilisation; running both paths every trip, "if-if", gave 29 %.)
+            // Only one code path runs per trip: a node step or ONE triangle test per lane (the vote is below).
+            // (The classic while-while shape made 64 lanes wait for the slowest lane to reach a leaf every
+            // round — 24 % VALU lane utilisation; running both paths every trip, "if-if", gave 29 %.)
             if (cur >= 0) {
                 if (steps >= budget) {
                     // node budget spent: suspend (or, if the pool is full, carry on)
@@ -467,6 +466,9 @@ void wf_drain(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
 // Host driver
 // ---------------------------------------------------------------------------------------
 extern "C" {
+
+// entries a ray's traversal stack can hold (LDS + global overflow); a 4-wide walk needs at most 3 per level + 2
+int ptk_wf_stack_capacity(void) { return ptd::kWfLdsStack + ptd::kWfOvfLevels; }
 
 // ---- work buffer: [ staging (all streams) | cohort 0 | cohort 1 | ... ] ----------------------
 static size_t cohort_bytes(size_t nStreams, int traceBlocks)
