@@ -256,9 +256,9 @@ void pt_scene_destroy(PtScene* s)
 int32_t pt_scene_num_lights(const PtScene* s) { return s ? s->n_lights : 0; }
 int64_t pt_scene_device_bytes(const PtScene* s) { return s ? s->bytes : 0; }
 
-// persistent grid of the traversal kernel: 256 CUs x 8 blocks of 4 waves = 8 waves/SIMD (PTAMD_TB overrides, tuning only;
-// measured: 1536 blocks -4 %, 1024 blocks -22 %)
-static const int kTraceBlocks = getenv("PTAMD_TB") ? atoi(getenv("PTAMD_TB")) : 2048;
+// persistent grid of the traversal kernel: 256 CUs x 7 blocks of 4 waves = 7 waves/SIMD, what its 72 VGPRs allow
+// (PTAMD_TB overrides, tuning only; measured: 1536 blocks -3 %, 1024 blocks -22 %)
+static const int kTraceBlocks = getenv("PTAMD_TB") ? atoi(getenv("PTAMD_TB")) : 1792;
 
 // ---- geometry of the tile split --------------------------------------------------------
 static int fill_params(const PtCamera* cam, const PtParams* prm, ptd::DevParams& d)

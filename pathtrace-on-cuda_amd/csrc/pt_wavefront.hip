@@ -37,11 +37,17 @@
 
 namespace ptd {
 
-constexpr int kWfLdsStack = 16;      // stack entries per lane kept in LDS (4 KB / wave -> 8 waves/SIMD fit)
+constexpr int kWfLdsStack = 16;      // stack entries per lane kept in LDS (4 KB / wave)
 constexpr int kWfOvfLevels = 48;     // further levels spill to global memory (never needed on the config scenes: 4-wide depth 12 -> at most 38 entries)
 constexpr int kWfChunk = 128;        // most ray ids a wave takes from a queue shard per atomic (measured optimum 116-229)
 constexpr int kWfRefill = 24;        // refill lanes once this many are idle (measured: 8..16 -2 %, 32 -0.4 %)
 constexpr int kDone = (int)0x80000000;
+// wf_trace's waves per SIMD.  7 (72 VGPRs) rather than 8 (64): the two-triangle leaf test needs the room, and
+// the kernel is bound by VALU issue, not by latency hiding (measured: 8 waves with 9 spilled registers and 6 waves
+// with none are both slower).
+#ifndef TRACE_WAVES
+#define TRACE_WAVES 7
+#endif
 // Time slicing: every launch is followed by a device-wide dependency (the shade kernel needs all
 // hits), so one ray that visits thousands of nodes would hold up the whole iteration (measured:
 // ~800 us per launch).  A ray that has visited kWfBudget nodes is therefore suspended — cur, sp,
@@ -122,7 +128,7 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
 // ---------------------------------------------------------------------------------------
 // STAT: a diagnostic build that also counts trips and the lanes they serve (pt_last_counters; PTAMD_TSTAT=1).
 template <bool STAT>
-__global__ __launch_bounds__(256, 8)
+__global__ __launch_bounds__(256, TRACE_WAVES)
 void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift, int triTrig, int refillMin,
               unsigned long long* stat, int statLaunch)
 {
@@ -342,13 +348,13 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     else { sp--; cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride]; }
                 }
             } else if (doTri && hasRay && pend != 0) {
-                // ---- one triangle of the parked leaf ----
+                // ---- the parked leaf: its (up to) two triangles in one go ----
                 const int code = ~pend, first = code >> 3, cnt = code & 7;
                 pend = 0;
                 if (cnt > 0) {
-                    tri_test(sc, first, org, dir, inv, degenerate, bestT, bestPrim);
+                    tri_test_pair(sc, first, cnt > 1, org, dir, inv, degenerate, bestT, bestPrim);
                     if (bestPrim >= 0 && bestT < stopBelow) { cur = kDone; sp = 0; }          // shadow ray: any occluder in front of the light will do
-                    else if (cnt > 1) pend = ~(((first + 1) << 3) | (cnt - 1));
+                    else if (cnt > 2) pend = ~(((first + 2) << 3) | (cnt - 2));
                 }
                 if (pend == 0 && cur < 0 && cur != kDone) {
                     // the ray was waiting with a second leaf: park that one, take the next stack entry
