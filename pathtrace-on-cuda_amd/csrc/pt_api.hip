@@ -46,7 +46,7 @@ void pt_set_error(const char* fmt, ...);   // pt_host.cpp
         }                                                                                   \
     } while (0)
 
-static const size_t kCounterBytes = 64 + 2700 * 3 * 8;   // 8 work counters + diagnostic launch timeline (3 x u64 per wf_trace launch)
+static const size_t kCounterBytes = 64 + 2700 * 3 * 8 + 32 * 8;   // 8 work counters + diagnostic launch timeline (3 x u64 per wf_trace launch)
 
 struct PtScene {
     int device = 0;
@@ -470,6 +470,7 @@ int pt_dbg_trace_timeline(PtScene* s, int64_t* out3n, int32_t n_launches)
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out3n, (const char*)s->d_counters + 64, (size_t)n_launches * 24, hipMemcpyDeviceToHost));
+    if (n_launches == 0 && out3n) HIPCHK(hipMemcpy(out3n, (const char*)s->d_counters + 64 + 2700 * 24, 32 * 8, hipMemcpyDeviceToHost));   // n = 0: the 32-bin histogram of wave lifetimes (32 us bins)
     return PT_OK;
 }
 

@@ -384,7 +384,12 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
             atomicAdd(&stat[0], stNodeTrips); atomicAdd(&stat[1], stNodeLanes); atomicAdd(&stat[2], stTriTrips); atomicAdd(&stat[3], stTriLanes);
             // launch timeline (100 MHz ticks): earliest wave start, earliest "queue empty", latest wave exit
             unsigned long long* tl = stat + 8 + 3 * (size_t)statLaunch;
-            atomicMax(&tl[0], ~stT0); if (stTExh) atomicMax(&tl[1], ~stTExh); atomicMax(&tl[2], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+            const unsigned long long tEnd = __builtin_amdgcn_s_memrealtime();
+            atomicMax(&tl[0], ~stT0); if (stTExh) atomicMax(&tl[1], ~stTExh); atomicMax(&tl[2], tEnd);
+            // distribution of wave exit times over the launch, all launches pooled: 16 bins of 1/16 of ... (absolute: 32 us bins)
+            unsigned long long* hist = stat + 8 + 3 * 2700;
+            const unsigned long long dtk = (tEnd - stT0) / 3200ull;      // 32 us bins (100 MHz ticks)
+            atomicAdd(&hist[dtk < 31 ? dtk : 31], 1ull);
             atomicAdd(&stat[4], stRefills); atomicAdd(&stat[5], stRefillLanes); atomicAdd(&stat[6], stNoRayLanes); atomicAdd(&stat[7], r);
         }
     }

@@ -28,3 +28,8 @@ print("launches %d: mean duration %.1f us (first wave start -> last wave exit); 
       (len(tl), dur.mean(), exh.mean(), (dur - exh).mean()))
 for lo, hi in ((0, 50), (len(tl) // 4, len(tl) // 4 + 50), (len(tl) // 2, len(tl) // 2 + 50), (3 * len(tl) // 4, 3 * len(tl) // 4 + 50)):
     print("  launches %4d-%4d: duration %.1f us, queue empty at %.1f us" % (lo, hi, dur[lo:hi].mean(), exh[lo:hi].mean()))
+import ctypes as C
+h = np.zeros(32, np.int64)
+ptamd.lib().pt_dbg_trace_timeline(sc._h, h.ctypes.data_as(C.c_void_p), 0)
+tot = max(1, int(h.sum()))
+print("wave lifetimes, 32-us bins (all launches pooled), % of waves:", " ".join("%.1f" % (100.0 * x / tot) for x in h[:24]))
