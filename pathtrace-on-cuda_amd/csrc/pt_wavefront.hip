@@ -58,9 +58,10 @@ constexpr int kSuspInts = 4 + kWfLdsStack + kWfOvfLevels;
 
 // block-aggregated append to four lists at once (live streams + one ray queue per kind): one atomicAdd
 // per list per block.  (One atomic per wave was the shade kernel's bottleneck: ~100k returning atomics
-// per launch on one cache line serialise at ~88 per microsecond; 768-thread blocks keep it to ~3k per list.)
+// per launch on one cache line serialise at ~88 per microsecond; with one atomic per 256-thread block and the
+// counters on separate lines they no longer show.)
 // Must be called by every thread of the block.
-constexpr int kShadeThreads = 1024;      // largest wf_shade workgroup (the default variant runs 768 = 3 waves/SIMD at 146 VGPRs, no spills)
+constexpr int kShadeThreads = 1024;      // largest wf_shade workgroup (the default runs 256-thread workgroups, 3 per CU at 146 VGPRs, no spills)
 constexpr int kLists = 1 + kRayKinds;
 PT_DEV void block_append(const bool e[kLists], uint32_t id, uint32_t* const c[kLists], uint32_t* const l[kLists])
 {
@@ -571,6 +572,9 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     static const int budgetShift = getenv("PTAMD_BS") ? atoi(getenv("PTAMD_BS")) : 14;
     static const int budgetMin = getenv("PTAMD_BM") ? atoi(getenv("PTAMD_BM")) : kWfBudget;
     static const int shadeWaves = getenv("PTAMD_SW") ? atoi(getenv("PTAMD_SW")) : 3;
+    // workgroup size of wf_shade: 256 threads = one wave per SIMD, so three (SW=3) workgroups share a CU and retire
+    // independently (measured: 64 -28 %, 128 -4 %, 192 -1 %, 384 -22 %, 512 -12 %, 768 -5 %)
+    static const int shadeThreads = (getenv("PTAMD_ST") && atoi(getenv("PTAMD_ST")) >= 64 && atoi(getenv("PTAMD_ST")) <= 512) ? (atoi(getenv("PTAMD_ST")) & ~63) : 256;
     static const int refillMin = getenv("PTAMD_RF") ? atoi(getenv("PTAMD_RF")) : kWfRefill;     // idle lanes that trigger a refill
     static const int triTrig = getenv("PTAMD_TT") ? atoi(getenv("PTAMD_TT")) : 64;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
@@ -588,9 +592,9 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             if (traceStat) hipLaunchKernelGGL(wf_trace<true>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, traceStat, it < 2700 ? it : 2699);
             else hipLaunchKernelGGL(wf_trace<false>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, (unsigned long long*)nullptr, 0);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
-            if (shadeWaves == 2) hipLaunchKernelGGL(wf_shade<2>, dim3((liveBound + 511) / 512), dim3(512), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
-            else if (shadeWaves == 3) hipLaunchKernelGGL(wf_shade<3>, dim3((liveBound + 767) / 768), dim3(768), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
-            else hipLaunchKernelGGL(wf_shade<4>, dim3((liveBound + 1023) / 1024), dim3(1024), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
+            if (shadeWaves == 2) hipLaunchKernelGGL(wf_shade<2>, dim3((liveBound + shadeThreads - 1) / shadeThreads), dim3(shadeThreads), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
+            else if (shadeWaves == 3) hipLaunchKernelGGL(wf_shade<3>, dim3((liveBound + shadeThreads - 1) / shadeThreads), dim3(shadeThreads), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
+            else hipLaunchKernelGGL(wf_shade<4>, dim3((liveBound + shadeThreads - 1) / shadeThreads), dim3(shadeThreads), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(h_cnt, &b.cnt[it % 3].nActive, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
