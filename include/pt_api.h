@@ -178,6 +178,7 @@ PT_API int  pt_render_timings(PtScene* s, float* ms_out, int32_t cap, int32_t re
  * pt_camera_basis = Camera::SetRotation + GetRight (srcs/camera.cpp:32-66).
  * -------------------------------------------------------------------------------- */
 PT_API int  pt_tonemap_u8(const float* raw_rgb, int64_t n_pixels, int32_t sample_cnt, uint8_t* rgb8);
+PT_API int  pt_convert_u8(const float* values, int64_t n, uint8_t* out);      /* ConverToUint8, include/image.h:5-8, element-wise */
 PT_API int  pt_write_png(const char* path, const uint8_t* data, int32_t W, int32_t H, int32_t channels);
 PT_API void pt_camera_basis(const float rot_deg[3], float forward[3], float up[3], float right[3]);
 
@@ -208,6 +209,13 @@ PT_API int  pt_dbg_math(int32_t device, const float* in, int32_t n, float* out8)
 /* Measurement aid: stream triad a = b + s*c over three float4 arrays of `bytes_per_array`
  * each, `iters` times; *gb_per_s = bytes moved (2 reads + 1 write per element) / time of the timed launches. */
 PT_API int  pt_dbg_triad(int32_t device, int64_t bytes_per_array, int32_t iters, double* gb_per_s);
+/* Measurement aid: the chip's vector-ALU issue rate, measured — every wave runs a long stream of independent
+ * instructions of one kind out of registers (op: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_max3_f32, 3 v_cvt_f32_ubyte1,
+ * 4 v_add_u32, 5 v_fma_f64, 6 v_cndmask_b32, 7 v_pk_mul_f32; +16 = lanes 32..63 masked off) at `waves_per_simd`
+ * waves per SIMD (1..8).  *wave_insts_per_s = wave-instructions retired per second chip-wide; *clock_ghz = shader
+ * clock during the run.  This is the denominator of bench.py's VALU roofline for the traversal kernel. */
+PT_API int  pt_dbg_valu_rate(int32_t device, int32_t op, int32_t waves_per_simd, int32_t iters,
+                             double* wave_insts_per_s, double* clock_ghz);
 /* Work counters of the last pt_render_tiles on this scene (int64 x 8):
  * [0] rays [1] node records fetched [2] triangle tests [3] sphere tests [4] rays with hit
  * [5] camera paths [6] loop trips of the wave scheduler [7] lane-trips with an active ray */

@@ -4,8 +4,8 @@
 TEST INFRASTRUCTURE.  Two kinds of fixture are written:
 
  * ref_*.npz   inputs + outputs of oracle/_ref/ptref, the partial build of the REAL
-               reference (srcs/bvh.cpp, srcs/CudaPrimitive.cu, include/CudaPrimitive.cuh,
-               include/CudaVector.cuh compiled unmodified — see oracle/Makefile).  These are
+               reference (srcs/bvh.cpp, srcs/CudaPrimitive.cu, srcs/camera.cpp, include/CudaPrimitive.cuh,
+               include/CudaVector.cuh, include/image.h compiled unmodified — see oracle/Makefile).  These are
                data (vectors), not reference source.
  * oracle_*.npz images / ray tables produced by the CPU restatement under the pinned
                contract (o_set_libm(1)); they pin the oracle against regressions and let
@@ -34,10 +34,32 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def gen_camera_u8():
+    """ref_camera.npz / ref_u8.npz: the REAL srcs/camera.cpp (Camera ctor + SetRotation + GetForward/GetUp/GetRight) and
+    include/image.h (ConverToUint8) through oracle/_ref/ptref.  Own random stream, so the other fixtures are untouched."""
+    rs = np.random.RandomState(4321)
+    rot = np.concatenate([
+        np.array([[0, 90, 0], [0, 0, 0], [0, 180, 0], [0, 90, 360], [0, 90, -90], [0, 200, 725], [0, -30, -725],
+                  [359.5, 45, 45], [-10, 135, 180], [0, 1e-3, 270], [0, 179.999, 90]], np.float32),
+        np.stack([rs.uniform(-400, 400, 500), rs.uniform(-20, 200, 500), rs.uniform(-800, 800, 500)], 1).astype(np.float32)])
+    np.savez_compressed(os.path.join(G, "ref_camera.npz"), rot=rot, basis=O.ref_camera(rot))
+    k = np.arange(0, 257, dtype=np.float64)
+    edges = (k / 255.99).astype(np.float32)                     # the values where the result steps, and their float neighbours
+    vals = np.concatenate([np.linspace(0.0, 1.0, 4097, dtype=np.float32), edges, np.nextafter(edges, np.float32(-1)), np.nextafter(edges, np.float32(2)),
+                           rs.uniform(0.0, 1.0, 4096).astype(np.float32)])
+    vals = vals[(vals >= 0.0) & (vals <= 1.0)]                   # ACESFilm saturates to [0,1]; outside it the cast is undefined behaviour
+    np.savez_compressed(os.path.join(G, "ref_u8.npz"), values=vals, u8=O.ref_u8(vals))
+    print("ref_camera.npz", rot.shape, "ref_u8.npz", vals.shape)
+
+
 def main():
     os.makedirs(G, exist_ok=True)
     if not O.have_ref():
         raise SystemExit("oracle/_ref/ptref missing: run `make -C oracle ref` first")
+    if len(sys.argv) > 1 and sys.argv[1] == "camera_u8":
+        gen_camera_u8()
+        return
+    gen_camera_u8()
     rs = np.random.RandomState(1234)
 
     # ---- G1: BVH build + flatten, real reference ----

@@ -89,6 +89,7 @@ int  o_render(void* scene, const OCamera* cam, const OParams* prm, float* accum_
               int64_t* counters, int nthreads);
 
 void o_tonemap(const float* raw_rgb, int n_pixels, int sample_cnt, unsigned char* rgb8);
+void o_u8(const float* v, int n, unsigned char* out);      /* ConverToUint8, include/image.h:5-8 */
 
 /* BxDF known-answer table.  lobe: 0 gltfpbr, 1 reflective, 2 refractive, 3 pure_refractive.
  * in  (28 f/row): normal(3) tangent(3) bitangent(3) frontface | albedo(3) specular(3)

@@ -5,6 +5,8 @@
 //   srcs/bvh.cpp           (SAHBVH::GenBVHTree / SplitNode / ConvertToBVH, IntoBVHNode)
 //   srcs/CudaPrimitive.cu  (LoadFromBVH flatten; compiled as host C++)
 //   srcs/glad.c            (GL loader table bvh.cpp refers to; never initialised)
+//   srcs/camera.cpp        (Camera::SetRotation / GetForward / GetUp / GetRight)
+//   include/image.h        (ConverToUint8; header-only — srcs/image.cpp needs stb and is not linked)
 // and the headers include/CudaPrimitive.cuh, CudaVector.cuh, CudaRay.cuh
 // (Triangle::Copy/hit, Sphere::hit, HitResult::SetNormal, vec3, reflect, refract).
 // <cuda_runtime.h> is the REAL header bundled with this image's triton wheel; no CUDA
@@ -28,6 +30,8 @@
 #include <string>
 
 #include "CudaPrimitive.cuh"   // reference header (pulls bvh.h, mesh.h, glm)
+#include "camera.h"            // reference header: class Camera (srcs/camera.cpp)
+#include "image.h"             // reference header: ConverToUint8
 
 // ---------------------------------------------------------------------------------
 static std::vector<unsigned char> slurp(const char* path)
@@ -207,6 +211,39 @@ static int cmd_sizes()
     return 0;
 }
 
+// camera rot.bin out.bin : rot = N x 3 floats (roll, pitch, yaw in degrees); out = N x 9 floats
+//   forward | up | right of a default-constructed reference Camera after SetRotation(rot)   (srcs/camera.cpp:22-66)
+static int cmd_camera(int argc, char** argv)
+{
+    if (argc != 4) return 1;
+    std::vector<unsigned char> in = slurp(argv[2]);
+    const size_t n = in.size() / 12;
+    const float* r = (const float*)in.data();
+    std::vector<float> out;
+    for (size_t i = 0; i < n; i++) {
+        Camera cam;
+        cam.SetRotation(glm::vec3(r[3 * i], r[3 * i + 1], r[3 * i + 2]));
+        const glm::vec3 f = cam.GetForward(), u = cam.GetUp(), rt = cam.GetRight();
+        const float v[9] = {f.x, f.y, f.z, u.x, u.y, u.z, rt.x, rt.y, rt.z};
+        out.insert(out.end(), v, v + 9);
+    }
+    spit(argv[3], out.data(), out.size() * 4);
+    return 0;
+}
+
+// u8 in.bin out.bin : N floats -> N bytes through ConverToUint8 (include/image.h:5-8)
+static int cmd_u8(int argc, char** argv)
+{
+    if (argc != 4) return 1;
+    std::vector<unsigned char> in = slurp(argv[2]);
+    const size_t n = in.size() / 4;
+    const float* v = (const float*)in.data();
+    std::vector<unsigned char> out(n);
+    for (size_t i = 0; i < n; i++) out[i] = ConverToUint8(v[i]);
+    spit(argv[3], out.data(), out.size());
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     int rc = 1;
@@ -217,7 +254,9 @@ int main(int argc, char** argv)
         else if (c == "sphit") rc = cmd_sphit(argc, argv);
         else if (c == "vecmath") rc = cmd_vecmath(argc, argv);
         else if (c == "sizes") rc = cmd_sizes();
+        else if (c == "camera") rc = cmd_camera(argc, argv);
+        else if (c == "u8") rc = cmd_u8(argc, argv);
     }
-    if (rc == 1) fprintf(stderr, "usage: ptref bvh|trihit|sphit|vecmath|sizes ...\n");
+    if (rc == 1) fprintf(stderr, "usage: ptref bvh|trihit|sphit|vecmath|sizes|camera|u8 ...\n");
     return rc;
 }

@@ -234,6 +234,7 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     sc->dev.nodes = (const float4*)sc->d_nodes; sc->dev.quad = (const uint4*)sc->d_quad; sc->dev.tri = (const float4*)sc->d_tri;
     sc->dev.leafbox = (const float4*)sc->d_leafbox; sc->dev.surf = (const float4*)sc->d_surf;
     sc->dev.lights = (const float4*)sc->d_lights; sc->dev.spheres = (const float4*)sc->d_spheres;
+    sc->dev.n_quad = accel.n_quad;
     sc->dev.n_nodes = n_wide; sc->dev.n_tris = n_tris; sc->dev.n_lights = n_lights; sc->dev.n_spheres = n_spheres;
     *out = sc;
     return PT_OK;

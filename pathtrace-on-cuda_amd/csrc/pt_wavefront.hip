@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <thread>
+#include <type_traits>
 #include <vector>
 #include "pt_device.h"
 #include "pt_math.h"
@@ -55,6 +56,16 @@ constexpr int kDone = (int)0x80000000;
 // launch resumes it.  hit.prim <= -2 encodes "pending, record = -2 - prim".
 constexpr int kWfBudget = 256;        // least node steps a ray may take per launch (measured: 96 cost 8 % on a 2M-stream render, >= 192 is flat)
 constexpr int kSuspInts = 4 + kWfLdsStack + kWfOvfLevels;
+// Top of the tree in LDS.  Every ray walks the first levels of the quad tree, and the kernel's vector-memory path is its
+// busiest unit (TA / TD ~70 % busy: each lane fetches its own 64-byte node, 4 x 16 B per lane per node step), so the
+// first kTopNodes nodes (breadth-first numbering, host/accel_build.cpp) are copied into LDS by every workgroup and
+// node steps on them read LDS instead.  80-byte stride: consecutive nodes start 20 banks apart, so the 16 lanes of
+// a ds_read_b128 group rarely collide.  Size: 16 KB of stacks + 6 KB of tree per workgroup, 7 workgroups per CU.
+#ifndef TRACE_TOP_NODES
+#define TRACE_TOP_NODES 0
+#endif
+constexpr int kTopNodes = TRACE_TOP_NODES > 0 ? TRACE_TOP_NODES : 1;
+constexpr int kTopStride = 5;         // uint4 per staged node
 
 // block-aggregated append to four lists at once (live streams + one ray queue per kind): one atomicAdd
 // per list per block.  (One atomic per wave was the shade kernel's bottleneck: ~100k returning atomics
@@ -63,18 +74,19 @@ constexpr int kSuspInts = 4 + kWfLdsStack + kWfOvfLevels;
 // Must be called by every thread of the block.
 constexpr int kShadeThreads = 1024;      // largest wf_shade workgroup (the default runs 256-thread workgroups, 3 per CU at 146 VGPRs, no spills)
 constexpr int kLists = 1 + kRayKinds;
-PT_DEV void block_append(const bool e[kLists], uint32_t id, uint32_t* const c[kLists], uint32_t* const l[kLists])
+template <int N>
+PT_DEV void block_append(const bool (&e)[N], uint32_t id, uint32_t* const (&c)[N], uint32_t* const (&l)[N])
 {
     constexpr int W = kShadeThreads / 64;
-    __shared__ uint32_t s_cnt[kLists][W];
-    __shared__ uint32_t s_base[kLists];
+    __shared__ uint32_t s_cnt[N][W];
+    __shared__ uint32_t s_base[N];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = (int)(blockDim.x >> 6);
-    unsigned long long m[kLists];
+    unsigned long long m[N];
 #pragma unroll
-    for (int k = 0; k < kLists; k++) { m[k] = __ballot(e[k]); if (lane == 0) s_cnt[k][wave] = __builtin_popcountll(m[k]); }
+    for (int k = 0; k < N; k++) { m[k] = __ballot(e[k]); if (lane == 0) s_cnt[k][wave] = __builtin_popcountll(m[k]); }
     __syncthreads();
-    if (threadIdx.x < kLists) {
+    if (threadIdx.x < N) {
         uint32_t tot = 0;
         for (int w = 0; w < nw; w++) tot += s_cnt[threadIdx.x][w];
         s_base[threadIdx.x] = tot ? atomicAdd(c[threadIdx.x], tot) : 0u;
@@ -82,7 +94,7 @@ PT_DEV void block_append(const bool e[kLists], uint32_t id, uint32_t* const c[kL
     __syncthreads();
     const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int k = 0; k < kLists; k++) {
+    for (int k = 0; k < N; k++) {
         uint32_t pos = s_base[k];
         for (int w = 0; w < wave; w++) pos += s_cnt[k][w];
         if (e[k]) l[k][pos + (uint32_t)__builtin_popcountll(m[k] & below)] = id;
@@ -115,7 +127,7 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
     const bool e[kLists] = {live, live, false, false};
     uint32_t* const c[kLists] = {&b.cnt[0].nActive, &b.cnt[0].nRays[0][0], &b.cnt[0].nRays[1][0], &b.cnt[0].nRays[2][0]};
     uint32_t* const l[kLists] = {b.active[0], b.rq[0], b.rq[1], b.rq[2]};
-    block_append(e, sid, c, l);
+    block_append<kLists>(e, sid, c, l);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -131,7 +143,7 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
 template <bool STAT>
 __global__ __launch_bounds__(256, TRACE_WAVES)
 void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift, int triTrig, int refillMin,
-              unsigned long long* stat, int statLaunch)
+              int topWant, unsigned long long* stat, int statLaunch)
 {
     const unsigned long long stT0 = STAT ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz
     unsigned long long stTExh = 0;
@@ -142,6 +154,12 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
     const uint32_t nKind1 = nPath + b.cnt[slot].nRays[1][0];
     const uint32_t n = nKind1 + b.cnt[slot].nRays[2][0];
     if ((uint32_t)blockIdx.x * 256u >= n) return;      // surplus blocks leave before touching the queue
+#if TRACE_TOP_NODES > 0
+    __shared__ uint4 lds_top[kTopNodes * kTopStride];
+    const int topN = min(min(topWant, kTopNodes), sc.n_quad);
+    for (int i = threadIdx.x; i < topN * 4; i += 256) lds_top[(i >> 2) * kTopStride + (i & 3)] = sc.quad[i];
+    __syncthreads();
+#endif
 
     const int lane = threadIdx.x & 63;
     int* stack = &lds_stack[threadIdx.x >> 6][lane];
@@ -292,9 +310,17 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 // of a coordinate share a dword), and the far side is cut at the closest hit.  The boxes only
                 // steer the search — acceptance is Triangle::hit + the reference's leaf box — so all that
                 // matters is that no box containing a point the ray reaches is ever rejected.
-                const uint4* np = sc.quad + 4 * (size_t)cur;
-                const uint4 n0 = np[0], n1 = np[1], n2 = np[2];
-                const uint2 n3 = *(const uint2*)(np + 3);
+                uint4 n0, n1, n2; uint2 n3;
+#if TRACE_TOP_NODES > 0
+                if (cur < topN) {
+                    const uint4* np = lds_top + cur * kTopStride;
+                    n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = *(const uint2*)(np + 3);
+                } else
+#endif
+                {
+                    const uint4* np = sc.quad + 4 * (size_t)cur;
+                    n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = *(const uint2*)(np + 3);
+                }
                 const int eb = (int)n0.w;
                 const float Ax = __builtin_ldexpf(inv.x, (int)(signed char)(eb & 0xff));
                 const float Ay = __builtin_ldexpf(inv.y, (int)(signed char)((eb >> 8) & 0xff));
@@ -435,7 +461,99 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
     const bool e[kLists] = {alive, emit[0], emit[1], emit[2]};
     uint32_t* const c[kLists] = {&b.cnt[slotOut].nActive, &b.cnt[slotOut].nRays[0][0], &b.cnt[slotOut].nRays[1][0], &b.cnt[slotOut].nRays[2][0]};
     uint32_t* const l[kLists] = {b.active[listIn ^ 1], b.rq[0], b.rq[1], b.rq[2]};
-    block_append(e, sid, c, l);
+    block_append<kLists>(e, sid, c, l);
+}
+
+// ---------------------------------------------------------------------------------------
+// wf_shade0 / wf_shade1: the same step as two launches (pt_stream.h: step_first / step_next).  wf_shade0 runs one thread
+// per live stream: NEE terms whose shadow rays are back, the current path's hit.  Streams that start a new sample in
+// this step (their path has just ended: about a quarter of them) are compacted into the `next` list and wf_shade1
+// shades the cached camera-ray hit for them in full waves; inside wf_shade that second hit ran at a quarter of the
+// lanes while the rest of the wave waited (profiles/r01_pmc_traffic.json: 45 % lane utilisation).
+// ---------------------------------------------------------------------------------------
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 256, WAVES)
+void wf_shade0(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, int slotOut, int slotClear, int listIn)
+{
+    const uint32_t nIn = b.cnt[slotIn].nActive;
+    if (blockIdx.x == 0) for (int k = threadIdx.x; k < kWfSlotBytes / 4; k += blockDim.x) ((uint32_t*)&b.cnt[slotClear])[k] = 0;
+    if ((uint32_t)blockIdx.x * blockDim.x >= nIn) return;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool have = idx < nIn;
+    bool alive = false, emit[kRayKinds] = {false, false, false}, toNext = false;
+    uint32_t sid = 0;
+    if (have) {
+        sid = b.active[listIn][idx];
+        SState st;
+        const float2 hitP = b.hit[0][sid], hitS = b.hit[1][sid], hitA = b.hit[2][sid];      // same fetch level as the state
+        load_state(b, sid, st);
+        // a ray of this stream is still being traversed (time-sliced): wait one iteration
+        const int pendP = (st.flags & F_PATH) ? __float_as_int(hitP.y) : -1, pendS = (st.flags & F_SHADOW) ? __float_as_int(hitS.y) : -1;
+        const int pendA = (st.flags & F_SHADOWA) ? __float_as_int(hitA.y) : -1;
+        if (pendP <= -2 || pendS <= -2 || pendA <= -2) {
+            alive = true; emit[0] = pendP <= -2; emit[1] = pendS <= -2; emit[2] = pendA <= -2;
+        } else {
+            float2 h0;
+            const int r = step_first(sc, cam, prm, b, sid, st, hitP, hitS, hitA, h0);
+            if (r == STEP_DONE) {
+                write_mean(b, prm, sid, st);
+            } else if (r == STEP_CONT) {
+                const uint32_t nf = st.flags;
+                store_state(b, sid, st);
+                alive = true;
+                emit[0] = (nf & F_PATH) != 0; emit[1] = (nf & F_SHADOW) != 0; emit[2] = (nf & F_SHADOWA) != 0;
+            } else {
+                // A new sample starts: wf_shade1 finishes the step.  The stream and its rays are queued HERE, so that every list
+                // keeps the order of the live list (neighbouring streams stay neighbours: their state loads coalesce and their
+                // rays walk the same nodes — appending them from wf_shade1 instead shuffled the lists and made both kernels
+                // 1.5-2x slower).  The path ray is queued before it is known to exist; wf_shade1 leaves a null ray if not.
+                b.rng0[sid] = make_uint4(st.rng.x0, st.rng.x1, st.rng.x2, st.rng.x3);
+                b.rng1[sid] = make_uint4(st.rng.x4, st.rng.d, ((uint32_t)st.toStart << 16), st.flags);
+                if (st.pixLoaded) b.pix[sid] = make_float4(st.pixelColor.x, st.pixelColor.y, st.pixelColor.z, 0.f);
+                toNext = true; alive = true;
+                emit[0] = true; emit[1] = true; emit[2] = (st.flags & F_SHADOWA) != 0;
+            }
+        }
+    }
+    const bool e[kLists + 1] = {alive, emit[0], emit[1], emit[2], toNext};
+    uint32_t* const c[kLists + 1] = {&b.cnt[slotOut].nActive, &b.cnt[slotOut].nRays[0][0], &b.cnt[slotOut].nRays[1][0], &b.cnt[slotOut].nRays[2][0], &b.cnt[slotOut].nNext};
+    uint32_t* const l[kLists + 1] = {b.active[listIn ^ 1], b.rq[0], b.rq[1], b.rq[2], b.next};
+    block_append<kLists + 1>(e, sid, c, l);
+}
+
+template <int LOBE>
+__global__ __launch_bounds__(256)
+void wf_shade1(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotOut)
+{
+    const uint32_t nIn = b.cnt[slotOut].nNext;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nIn) return;
+    const uint32_t sid = b.next[idx];
+    const uint4 r0 = b.rng0[sid], r1 = b.rng1[sid];
+    const float4 d0 = b.dir0[sid];
+    const float2 h0 = b.hit0[sid];
+    SState st;
+    st.rng.x0 = r0.x; st.rng.x1 = r0.y; st.rng.x2 = r0.z; st.rng.x3 = r0.w; st.rng.x4 = r1.x; st.rng.d = r1.y;
+    st.toStart = (int)(r1.z >> 16); st.flags = r1.w;
+    step_next<LOBE>(sc, cam, prm, st, h0, f3(d0.x, d0.y, d0.z));
+    const uint32_t nf = st.flags;
+    b.rng0[sid] = make_uint4(st.rng.x0, st.rng.x1, st.rng.x2, st.rng.x3);
+    b.rng1[sid] = make_uint4(st.rng.x4, st.rng.d, ((uint32_t)st.toStart << 16) | ((uint32_t)st.depth << 8) | (uint32_t)st.refractCnt, nf);
+    b.weight[sid] = make_float4(st.weight.x, st.weight.y, st.weight.z, st.cosA);
+    b.rad[sid] = make_float4(st.radiance.x, st.radiance.y, st.radiance.z, st.denom);
+    b.ray_o[1][sid] = make_float4(st.shO.x, st.shO.y, st.shO.z, st.shTmax);
+    b.ray_d[1][sid] = make_float4(st.shD.x, st.shD.y, st.shD.z, 0.f);
+    b.wb[sid] = make_float4(st.wb.x, st.wb.y, st.wb.z, 0.f);
+    b.lp[sid] = make_float4(st.lightP.x, st.lightP.y, st.lightP.z, 0.f);
+    if (nf & F_PATH) {
+        b.ray_o[0][sid] = make_float4(st.pathO.x, st.pathO.y, st.pathO.z, 999999.f);
+        b.ray_d[0][sid] = make_float4(st.pathD.x, st.pathD.y, st.pathD.z, 0.f);
+    } else {
+        // the sample ended at its first hit: the path ray wf_shade0 queued for it is a null ray (t_max < 0: nothing can be hit,
+        // one node step), and without F_PATH nobody reads its result
+        b.ray_o[0][sid] = make_float4(0.f, 0.f, 0.f, -1.f);
+        b.ray_d[0][sid] = make_float4(0.57735026f, 0.57735026f, 0.57735026f, 0.f);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -490,7 +608,7 @@ static size_t cohort_bytes(size_t nStreams, int traceBlocks)
     b += n16 * 16 * 11;                       // 11 float4 state arrays
     b += n16 * 16 * 2 * ptd::kRayKinds;       // ray_o/ray_d per kind
     b += n16 * 8 * (ptd::kRayKinds + 1);      // hits per kind + the cached camera-ray hit
-    b += n16 * 4 * (2 + ptd::kRayKinds);      // active x2, one ray queue per kind
+    b += n16 * 4 * (3 + ptd::kRayKinds);      // active x2, one ray queue per kind, the next-sample list
     b += 3 * ptd::kWfSlotBytes; // counters
     b += (size_t)traceBlocks * 256 * ptd::kWfOvfLevels * 4;
     b += 2 * ((nStreams / 4 + 1024) * ptd::kSuspInts * 4 + 16);
@@ -533,6 +651,7 @@ static void carve(char* p, size_t nStreams, int traceBlocks, ptd::WfBuf& b)
     b.hit0 = (float2*)take(n16 * 8);
     for (int k = 0; k < 2; k++) b.active[k] = (uint32_t*)take(n16 * 4);
     for (int k = 0; k < ptd::kRayKinds; k++) b.rq[k] = (uint32_t*)take(n16 * 4);
+    b.next = (uint32_t*)take(n16 * 4);
     b.cnt = (ptd::WfCounters*)take(3 * ptd::kWfSlotBytes);
     b.ovf = (int*)take((size_t)traceBlocks * 256 * ptd::kWfOvfLevels * 4);
     b.suspCap = (uint32_t)(nStreams / 4 + 1024);
@@ -578,6 +697,8 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     static const int refillMin = getenv("PTAMD_RF") ? atoi(getenv("PTAMD_RF")) : kWfRefill;     // idle lanes that trigger a refill
     static const int triTrig = getenv("PTAMD_TT") ? atoi(getenv("PTAMD_TT")) : 64;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
+    static const int topNodes = getenv("PTAMD_TOP") ? atoi(getenv("PTAMD_TOP")) : kTopNodes;      // quad nodes staged in LDS (0 = none)
+    static const bool splitShade = getenv("PTAMD_SPLIT") ? atoi(getenv("PTAMD_SPLIT")) != 0 : false;     // wf_shade0 + wf_shade1 instead of wf_shade
     unsigned long long* const traceStat = g_traceStat;
     int it = 0;
     int poll = 16;
@@ -589,12 +710,20 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
             const bool timed = trace_ev && it < trace_ev_pairs;
             if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
-            if (traceStat) hipLaunchKernelGGL(wf_trace<true>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, traceStat, it < 2700 ? it : 2699);
-            else hipLaunchKernelGGL(wf_trace<false>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, (unsigned long long*)nullptr, 0);
+            if (traceStat) hipLaunchKernelGGL(wf_trace<true>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
+            else hipLaunchKernelGGL(wf_trace<false>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, 0);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
-            if (shadeWaves == 2) hipLaunchKernelGGL(wf_shade<2>, dim3((liveBound + shadeThreads - 1) / shadeThreads), dim3(shadeThreads), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
-            else if (shadeWaves == 3) hipLaunchKernelGGL(wf_shade<3>, dim3((liveBound + shadeThreads - 1) / shadeThreads), dim3(shadeThreads), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
-            else hipLaunchKernelGGL(wf_shade<4>, dim3((liveBound + shadeThreads - 1) / shadeThreads), dim3(shadeThreads), 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
+            const dim3 sg((liveBound + shadeThreads - 1) / shadeThreads), sb(shadeThreads);
+            if (!splitShade) {
+                if (shadeWaves == 2) hipLaunchKernelGGL(wf_shade<2>, sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
+                else if (shadeWaves == 3) hipLaunchKernelGGL(wf_shade<3>, sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
+                else hipLaunchKernelGGL(wf_shade<4>, sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
+            } else {
+                if (shadeWaves == 2) hipLaunchKernelGGL(wf_shade0<2>, sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
+                else if (shadeWaves == 3) hipLaunchKernelGGL(wf_shade0<3>, sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
+                else hipLaunchKernelGGL(wf_shade0<4>, sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
+                hipLaunchKernelGGL(wf_shade1<-1>, dim3((liveBound + 255) / 256), dim3(256), 0, stream, *sc, *cam, prm, b, sOut);
+            }
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(h_cnt, &b.cnt[it % 3].nActive, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;

@@ -326,6 +326,33 @@ void pt_build_accel(const PtBVHNode* rnodes, int n_rnodes, const PtTriangle* tri
         Emit em{b, quad, absPad, quadDepth};
         em.run(0, 0);
     }
+    // Renumber: the first kQuadTopBfs nodes in breadth-first order — every ray walks them, and wf_trace keeps a prefix of
+    // them in LDS (any node index below its prefix length is an LDS read) — the rest keep their depth-first order
+    // (a subtree stays contiguous in memory).
+    {
+        const size_t n = quad.size();
+        static const int kBfs = getenv("PTAMD_BFS") ? atoi(getenv("PTAMD_BFS")) : kQuadTopBfs;      // tuning / A-B only
+        std::vector<int> order; order.reserve(n);
+        std::vector<char> placed(n, 0);
+        order.push_back(0); placed[0] = 1;
+        for (size_t head = 0; head < order.size() && order.size() < (size_t)kBfs; head++) {
+            const Q4& q = quad[(size_t)order[head]];
+            for (int k = 0; k < 4 && order.size() < (size_t)kBfs; k++) {
+                const int r = (int)q.d[4 + k];
+                if (r >= 0 && !placed[(size_t)r]) { placed[(size_t)r] = 1; order.push_back(r); }
+            }
+        }
+        for (size_t i = 0; i < n; i++) if (!placed[i]) order.push_back((int)i);
+        std::vector<int> newIdx(n);
+        for (size_t i = 0; i < n; i++) newIdx[(size_t)order[i]] = (int)i;
+        std::vector<Q4> re(n);
+        for (size_t i = 0; i < n; i++) {
+            Q4 q = quad[(size_t)order[i]];
+            for (int k = 0; k < 4; k++) if ((int)q.d[4 + k] >= 0) q.d[4 + k] = (uint32_t)newIdx[(size_t)q.d[4 + k]];
+            re[i] = q;
+        }
+        quad.swap(re);
+    }
     out.quad.resize(quad.size() * 16);
     memcpy(out.quad.data(), quad.data(), quad.size() * sizeof(Q4));
     out.n_quad = (int)quad.size();

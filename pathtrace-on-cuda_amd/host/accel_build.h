@@ -4,6 +4,7 @@
 #include <vector>
 #include "../../include/pt_api.h"
 
+constexpr int kQuadTopBfs = 1024;       // leading quad nodes numbered breadth-first (wf_trace stages a prefix of them in LDS)
 constexpr int kAccelMaxDepth = 32;       // == ptd::kStackDepth; the builder never exceeds it
 
 struct PtAccel {

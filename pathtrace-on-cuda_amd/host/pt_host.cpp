@@ -43,6 +43,15 @@ void pt_params_default(PtParams* p)
 // exportImage (srcs/pathtracer.cu:94-112): c = raw / SampleCnt (vec3::operator/=, which
 // multiplies by a reciprocal taken in double, include/CudaVector.cuh:151-158), ACESFilm
 // (include/CudaUtil.cuh:383-391), ConverToUint8 = (uchar)(v * 255.99f) (include/image.h:5-8).
+// ConverToUint8, include/image.h:5-8 (pinned by the real reference: tests/golden/ref_u8.npz)
+static inline unsigned char convert_u8(float value) { return (unsigned char)(value * 255.99f); }
+int pt_convert_u8(const float* values, int64_t n, uint8_t* out)
+{
+    if (!values || !out || n < 0) { pt_set_error("pt_convert_u8: bad argument"); return PT_ERR_INVALID; }
+    for (int64_t i = 0; i < n; i++) out[i] = convert_u8(values[i]);
+    return PT_OK;
+}
+
 int pt_tonemap_u8(const float* raw_rgb, int64_t n_pixels, int32_t sample_cnt, uint8_t* rgb8)
 {
     if (!raw_rgb || !rgb8 || n_pixels < 0 || sample_cnt < 1) { pt_set_error("pt_tonemap_u8: bad argument"); return PT_ERR_INVALID; }
@@ -53,7 +62,7 @@ int pt_tonemap_u8(const float* raw_rgb, int64_t n_pixels, int32_t sample_cnt, ui
         const float den = x * (2.43f * x + 0.59f) + 0.14f;
         const float q = num / den;
         const float s = (q > 0.f) ? ((q < 1.f) ? q : 1.f) : 0.f;      // saturate, CudaVector.cuh:296-303
-        rgb8[i] = (unsigned char)(s * 255.99f);
+        rgb8[i] = convert_u8(s);
     }
     return PT_OK;
 }

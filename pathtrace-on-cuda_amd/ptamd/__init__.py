@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(PKG_ROOT, "libptamd.so")
+LIB_PATH = os.environ.get("PTAMD_LIB") or os.path.join(PKG_ROOT, "libptamd.so")      # PTAMD_LIB: A/B builds of the same library
 
 PRIM_FLOATS = 84      # sizeof(PtPrimitive) / 4   (3 x 112-byte Vertex, include/mesh.h:21-37)
 TRI_FLOATS = 88       # sizeof(PtTriangle) / 4
@@ -68,6 +68,7 @@ API = [
     ("pt_last_render_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
     ("pt_render_timings", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     ("pt_tonemap_u8", C.c_int, [_P, C.c_int64, C.c_int32, _P]),
+    ("pt_convert_u8", C.c_int, [_P, C.c_int64, _P]),
     ("pt_write_png", C.c_int, [C.c_char_p, _P, C.c_int32, C.c_int32, C.c_int32]),
     ("pt_camera_basis", None, [C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3)]),
     ("pt_scene_gen", C.c_int32, [C.c_int32, C.c_int32, _P, C.c_int32]),
@@ -77,6 +78,7 @@ API = [
     ("pt_dbg_rng", C.c_int, [C.c_int32, C.c_uint64, C.c_int32, _P, _P]),
     ("pt_dbg_math", C.c_int, [C.c_int32, _P, C.c_int32, _P]),
     ("pt_dbg_triad", C.c_int, [C.c_int32, C.c_int64, C.c_int32, _P]),
+    ("pt_dbg_valu_rate", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("pt_last_counters", C.c_int, [_P, _P]),
     ("pt_dbg_trace_timeline", C.c_int, [_P, _P, C.c_int32]),
     ("pt_enable_counters", C.c_int, [_P, C.c_int32]),
@@ -180,6 +182,14 @@ def tonemap_u8(raw_rgb, sample_cnt):
     raw = np.ascontiguousarray(raw_rgb, np.float32)
     out = np.zeros(raw.shape, np.uint8)
     _check(lib().pt_tonemap_u8(_ptr(raw), raw.size // 3, sample_cnt, _ptr(out)), "pt_tonemap_u8")
+    return out
+
+
+def convert_u8(values):
+    """ConverToUint8 (include/image.h:5-8), element-wise."""
+    v = np.ascontiguousarray(values, np.float32)
+    out = np.zeros(v.shape, np.uint8)
+    _check(lib().pt_convert_u8(_ptr(v), v.size, _ptr(out)), "pt_convert_u8")
     return out
 
 
@@ -339,6 +349,15 @@ def triad_gbps(bytes_per_array=1 << 30, iters=10, device=0):
     out = C.c_double(0.0)
     _check(lib().pt_dbg_triad(int(device), int(bytes_per_array), int(iters), C.byref(out)), "pt_dbg_triad")
     return float(out.value)
+
+
+def valu_rate(op=0, waves_per_simd=4, iters=20000, device=0):
+    """Measured VALU issue rate: (wave-instructions per second chip-wide, shader clock in GHz) for one instruction kind
+    (pt_dbg_valu_rate: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_max3_f32, 3 v_cvt_f32_ubyte1, 4 v_add_u32, 5 v_fma_f64, 6 v_cndmask_b32,
+    7 v_pk_mul_f32; +16 = half the lanes masked off)."""
+    r, g = C.c_double(0.0), C.c_double(0.0)
+    _check(lib().pt_dbg_valu_rate(int(device), int(op), int(waves_per_simd), int(iters), C.byref(r), C.byref(g)), "pt_dbg_valu_rate")
+    return float(r.value), float(g.value)
 
 
 def dbg_math(x, device=0):

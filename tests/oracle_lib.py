@@ -63,6 +63,7 @@ def lib():
         l.o_render.restype = C.c_int
         l.o_render.argtypes = [P, C.POINTER(OCamera), C.POINTER(OParams), P, P, C.c_int]
         l.o_tonemap.argtypes = [P, C.c_int, C.c_int, P]
+        l.o_u8.argtypes = [P, C.c_int, P]
         l.o_bxdf.argtypes = [C.c_int, P, C.c_int, P]
         _lib = l
     return _lib
@@ -192,6 +193,13 @@ def tonemap(raw, sample_cnt):
     return out
 
 
+def u8(values):
+    v = np.ascontiguousarray(values, np.float32)
+    out = np.zeros(v.shape, np.uint8)
+    lib().o_u8(_p(v), v.size, _p(out))
+    return out
+
+
 def bxdf(lobe, in28):
     in28 = np.ascontiguousarray(in28, np.float32).reshape(-1, 28)
     out = np.zeros((in28.shape[0], 12), np.float32)
@@ -237,3 +245,15 @@ def ref_sphere_hit(sph16, rays10):
 def ref_vecmath(in7):
     (o,) = _run_ref("vecmath", [np.ascontiguousarray(in7, np.float32)], [np.float32])
     return o.reshape(-1, 21)
+
+
+def ref_camera(rot3):
+    """forward | up | right (9 floats) of the reference's Camera after SetRotation(rot) — real srcs/camera.cpp."""
+    (o,) = _run_ref("camera", [np.ascontiguousarray(rot3, np.float32)], [np.float32])
+    return o.reshape(-1, 9)
+
+
+def ref_u8(values):
+    """ConverToUint8 of the real include/image.h."""
+    (o,) = _run_ref("u8", [np.ascontiguousarray(values, np.float32)], [np.uint8])
+    return o

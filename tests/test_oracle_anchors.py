@@ -39,6 +39,13 @@ def test_standin_anchor(golden_dir):
     assert abs(cnt[1] / cnt[0] - 166.4) < 0.1 and abs(cnt[2] / cnt[0] - 174.8) < 0.1
 
 
+def test_standin4x_anchor(golden_dir):
+    """The third anchor of SURVEY.md Appendix A: four instanced stand-ins (278,268 triangles), 320x180, 1 x 4 spp."""
+    a = json.load(open(os.path.join(golden_dir, "anchors.json")))
+    m, cnt = _mean(2, 320, 180, 4)
+    assert f"{m:.6f}" == f"{a['standin4_320x180_1x4']:.6f}"
+
+
 def test_golden_images_are_stable(golden_dir):
     """The committed oracle images (pinned contract, correctly-rounded libm) regenerate bit for bit."""
     for name, kind in (("cornell", 0), ("standin24", 1), ("standin24_spheres", 1)):

@@ -58,6 +58,26 @@ def test_vec3_matches_reference_golden(golden_dir):
     assert np.array_equal(bits(O.vecmath(g["in7"])), bits(g["out21"]))
 
 
+def test_camera_matches_reference_golden(golden_dir):
+    """Camera ctor + SetRotation + GetForward/GetUp/GetRight of the REAL srcs/camera.cpp (ptref camera): the oracle's
+    restatement and the product's pt_camera_basis both reproduce it bit for bit, clamps and wrap-arounds included."""
+    g = np.load(os.path.join(golden_dir, "ref_camera.npz"))
+    assert g["rot"].shape[0] > 500
+    for rot, want in zip(g["rot"], g["basis"]):
+        o = np.concatenate(O.camera_basis(tuple(rot)))
+        p = np.concatenate(ptamd.camera_basis(tuple(rot)))
+        assert np.array_equal(bits(o), bits(want)), rot
+        assert np.array_equal(bits(p), bits(want)), rot
+
+
+def test_convert_u8_matches_reference_golden(golden_dir):
+    """ConverToUint8 of the REAL include/image.h (ptref u8) over [0,1], every step edge and its float neighbours."""
+    g = np.load(os.path.join(golden_dir, "ref_u8.npz"))
+    assert set(np.unique(g["u8"])) == set(range(256))
+    assert np.array_equal(O.u8(g["values"]), g["u8"])
+    assert np.array_equal(ptamd.convert_u8(g["values"]), g["u8"])
+
+
 @pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref/ptref not built (reference tree absent)")
 def test_live_against_reference_binary():
     rs = np.random.RandomState(99)
@@ -71,6 +91,10 @@ def test_live_against_reference_binary():
     sph = random_spheres16(5, rs)
     rays = random_rays10(1000, 5, None, rs, spheres=sph)
     assert np.array_equal(bits(O.ref_sphere_hit(sph, rays)), bits(O.sphere_hit(sph, rays)))
+    rot = np.stack([rs.uniform(-400, 400, 64), rs.uniform(-20, 200, 64), rs.uniform(-800, 800, 64)], 1).astype(np.float32)
+    assert np.array_equal(bits(O.ref_camera(rot)), bits(np.stack([np.concatenate(O.camera_basis(tuple(r))) for r in rot])))
+    v = rs.uniform(0, 1, 4096).astype(np.float32)
+    assert np.array_equal(O.ref_u8(v), O.u8(v))
     prims = ptamd.gen_scene(2, 187)                          # 278k triangles, deep tree
     n_r, t_r = O.ref_bvh(prims)
     n_o, t_o, _ = O.bvh_build(prims)
