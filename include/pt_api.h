@@ -171,6 +171,29 @@ PT_API int  pt_last_render_ms(PtScene* s, float* ms);
 PT_API int  pt_render_timings(PtScene* s, float* ms_out, int32_t cap, int32_t reset);
 
 /* ----------------------------------------------------------------------------------
+ * (e) Multi-GPU exchange (new: the reference is single-device, srcs/pathtracer.cu:124-259).  One process per GPU; rank r
+ * renders tiles t % world == r with pt_render_tiles, then ONE collective — a gather of the tile buffers to rank 0,
+ * RCCL ncclGather (rccl.h:745) over xGMI — and pt_untile on rank 0 assemble the frame.  No torch, no MPI needed:
+ *   rank 0:  pt_comm_unique_id(id) and hand the 128 bytes to the other processes (any channel), or let
+ *            pt_comm_create_from_file do it through a file for the processes of one node;
+ *   all:     pt_comm_create(id, rank, world, device, &comm); ... pt_render_tiles(...);
+ *            pt_gather_frame(comm, d_tiles, &cam, &prm, d_gathered, d_frame, stream);   (both asynchronous on `stream`)
+ * world == 1 never loads RCCL (the gather is a device copy).  INTEGRATION.md shows the 8-process C++ use.
+ * -------------------------------------------------------------------------------- */
+#define PT_COMM_ID_BYTES 128
+typedef struct PtComm PtComm;
+PT_API int  pt_comm_unique_id(uint8_t id[PT_COMM_ID_BYTES]);
+PT_API int  pt_comm_create(const uint8_t id[PT_COMM_ID_BYTES], int32_t rank, int32_t world, int32_t device, PtComm** out);
+PT_API int  pt_comm_create_from_file(const char* path, int32_t rank, int32_t world, int32_t device, int32_t timeout_s, PtComm** out);
+PT_API void pt_comm_destroy(PtComm* c);
+PT_API int32_t pt_comm_rank(const PtComm* c);
+PT_API int32_t pt_comm_world(const PtComm* c);
+/* d_gathered: rank 0 only (NULL elsewhere), world x n_floats floats, rank-major — what pt_untile reads. */
+PT_API int  pt_gather_tiles(PtComm* c, const float* d_tiles, int64_t n_floats, float* d_gathered, void* hip_stream);
+PT_API int  pt_gather_frame(PtComm* c, const float* d_tiles, const PtCamera* cam, const PtParams* prm,
+                            float* d_gathered, float* d_frame_rgb, void* hip_stream);
+
+/* ----------------------------------------------------------------------------------
  * (a12,a13) Output + camera helpers (host).
  * pt_tonemap_u8 = exportImage (srcs/pathtracer.cu:94-112): /SampleCnt, ACESFilm
  *   (include/CudaUtil.cuh:383-391), ConverToUint8 (include/image.h:5-8).

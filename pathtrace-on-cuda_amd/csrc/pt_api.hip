@@ -194,6 +194,11 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
             n_lights++;
         }
     }
+    // dead-NEE-term pruning (pt_stream.h: bounce) needs every emittance a shadow ray can return to be finite and non-negative
+    bool emitOk = true;
+    auto okE = [](const float* e) { return std::isfinite(e[0]) && std::isfinite(e[1]) && std::isfinite(e[2]) && e[0] >= 0.f && e[1] >= 0.f && e[2] >= 0.f; };
+    for (int i = 0; i < n_tris; i++) emitOk = emitOk && okE(tris[i].mat0.emittance);
+    for (int i = 0; i < n_spheres; i++) emitOk = emitOk && okE(spheres[i].mat.emittance);
     std::vector<float> sph((size_t)n_spheres * 16);
     for (int i = 0; i < n_spheres; i++) {
         const PtSphere& s = spheres[i];
@@ -235,6 +240,7 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     sc->dev.leafbox = (const float4*)sc->d_leafbox; sc->dev.surf = (const float4*)sc->d_surf;
     sc->dev.lights = (const float4*)sc->d_lights; sc->dev.spheres = (const float4*)sc->d_spheres;
     sc->dev.n_quad = accel.n_quad;
+    sc->dev.nee_prune = (emitOk && !(getenv("PTAMD_PRUNE") && atoi(getenv("PTAMD_PRUNE")) == 0)) ? 1 : 0;      // PTAMD_PRUNE=0: A/B only
     sc->dev.n_nodes = n_wide; sc->dev.n_tris = n_tris; sc->dev.n_lights = n_lights; sc->dev.n_spheres = n_spheres;
     *out = sc;
     return PT_OK;

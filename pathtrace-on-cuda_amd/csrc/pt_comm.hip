@@ -1,0 +1,184 @@
+// pt_comm.hip — the multi-GPU exchange step of the C-ABI (include/pt_api.h: pt_comm_*, pt_gather_tiles, pt_gather_frame).
+//
+// The reference is single-device (srcs/pathtracer.cu:124-259 never calls cudaSetDevice and has no collective).  Here one
+// process drives one GPU, every rank renders its interleaved 8x8 tiles for all passes (pt_render_tiles) and the ONLY
+// data-path collective is one gather of the finished tile buffers to rank 0 — RCCL's ncclGather (rccl.h:745) over xGMI:
+// 3.1 MB per rank at 1080p, each of root's seven links carries exactly one peer's buffer — followed by pt_untile on
+// rank 0.  This file gives the C++ host surface that step without Python or torch.distributed.
+//
+// RCCL is loaded with dlopen on first use by a communicator of world > 1, so a single-GPU user of libptamd.so never
+// loads or initialises it.  Bootstrap: rank 0 makes a 128-byte id (pt_comm_unique_id) and hands it to the other
+// processes by whatever channel the host application has; pt_comm_create_from_file does it through a file for
+// processes of one node (rank 0 writes, the others wait for it).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <unistd.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/pt_api.h"
+
+void pt_set_error(const char* fmt, ...);   // pt_host.cpp
+
+static_assert(PT_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "PT_COMM_ID_BYTES must match ncclUniqueId");
+
+namespace {
+
+struct Rccl {
+    void* so = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl* rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.so) break;
+        }
+        if (r.so) {
+            r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.so, "ncclGetUniqueId");
+            r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.so, "ncclCommInitRank");
+            r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.so, "ncclCommDestroy");
+            r.Gather = (decltype(r.Gather))dlsym(r.so, "ncclGather");
+            r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.so, "ncclGetErrorString");
+            if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Gather || !r.GetErrorString) { dlclose(r.so); r.so = nullptr; }
+        }
+    }
+    return r.so ? &r : nullptr;
+}
+
+}  // namespace
+
+struct PtComm {
+    int rank = 0, world = 1, device = 0;
+    ncclComm_t comm = nullptr;
+};
+
+#define NCCLCHK(expr)                                                                                   \
+    do {                                                                                                \
+        ncclResult_t r_ = (expr);                                                                       \
+        if (r_ != ncclSuccess) { pt_set_error("RCCL error at %s:%d '%s': %s", __FILE__, __LINE__, #expr, R->GetErrorString(r_)); return PT_ERR_DEVICE; } \
+    } while (0)
+#define HIPCHK(expr)                                                                                    \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) { pt_set_error("HIP error %d at %s:%d '%s': %s", (int)e_, __FILE__, __LINE__, #expr, hipGetErrorString(e_)); return PT_ERR_DEVICE; } \
+    } while (0)
+
+extern "C" {
+
+int pt_comm_unique_id(uint8_t id[PT_COMM_ID_BYTES])
+{
+    if (!id) { pt_set_error("pt_comm_unique_id: NULL"); return PT_ERR_INVALID; }
+    Rccl* R = rccl();
+    if (!R) { pt_set_error("pt_comm_unique_id: librccl.so could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing"); return PT_ERR_UNSUPPORTED; }
+    ncclUniqueId u;
+    NCCLCHK(R->GetUniqueId(&u));
+    memcpy(id, u.internal, PT_COMM_ID_BYTES);
+    return PT_OK;
+}
+
+int pt_comm_create(const uint8_t id[PT_COMM_ID_BYTES], int32_t rank, int32_t world, int32_t device, PtComm** out)
+{
+    if (!out) { pt_set_error("pt_comm_create: out is NULL"); return PT_ERR_INVALID; }
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && !id)) { pt_set_error("pt_comm_create: bad rank %d / world %d", rank, world); return PT_ERR_INVALID; }
+    PtComm* c = new PtComm();
+    c->rank = rank; c->world = world; c->device = device;
+    if (world > 1) {
+        Rccl* R = rccl();
+        if (!R) { delete c; pt_set_error("pt_comm_create: librccl.so could not be loaded"); return PT_ERR_UNSUPPORTED; }
+        if (hipSetDevice(device) != hipSuccess) { delete c; pt_set_error("pt_comm_create: hipSetDevice(%d) failed", device); return PT_ERR_DEVICE; }
+        ncclUniqueId u;
+        memcpy(u.internal, id, PT_COMM_ID_BYTES);
+        ncclResult_t r = R->CommInitRank(&c->comm, world, u, rank);
+        if (r != ncclSuccess) { pt_set_error("ncclCommInitRank(rank %d of %d): %s", rank, world, R->GetErrorString(r)); delete c; return PT_ERR_DEVICE; }
+    }
+    *out = c;
+    return PT_OK;
+}
+
+// Rank 0 writes the id to `path` (temporary name + rename, so a reader never sees half of it); the other ranks wait for the
+// file (up to timeout_s seconds).  The file is left in place: remove it before reusing the path for another job.
+int pt_comm_create_from_file(const char* path, int32_t rank, int32_t world, int32_t device, int32_t timeout_s, PtComm** out)
+{
+    if (!path || !out) { pt_set_error("pt_comm_create_from_file: NULL argument"); return PT_ERR_INVALID; }
+    uint8_t id[PT_COMM_ID_BYTES];
+    memset(id, 0, sizeof(id));
+    if (world > 1) {
+        if (rank == 0) {
+            int rc = pt_comm_unique_id(id);
+            if (rc) return rc;
+            const std::string tmp = std::string(path) + ".tmp";
+            FILE* f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) { if (f) fclose(f); pt_set_error("pt_comm_create_from_file: cannot write %s", tmp.c_str()); return PT_ERR_IO; }
+            fclose(f);
+            if (rename(tmp.c_str(), path) != 0) { pt_set_error("pt_comm_create_from_file: cannot rename to %s", path); return PT_ERR_IO; }
+        } else {
+            bool got = false;
+            for (int waited_ms = 0; waited_ms <= timeout_s * 1000; waited_ms += 20) {
+                FILE* f = fopen(path, "rb");
+                if (f) { got = fread(id, 1, sizeof(id), f) == sizeof(id); fclose(f); if (got) break; }
+                usleep(20000);
+            }
+            if (!got) { pt_set_error("pt_comm_create_from_file: rank %d timed out waiting for %s", rank, path); return PT_ERR_IO; }
+        }
+    }
+    return pt_comm_create(id, rank, world, device, out);
+}
+
+void pt_comm_destroy(PtComm* c)
+{
+    if (!c) return;
+    if (c->comm) { Rccl* R = rccl(); if (R) (void)R->CommDestroy(c->comm); }
+    delete c;
+}
+
+int32_t pt_comm_rank(const PtComm* c) { return c ? c->rank : -1; }
+int32_t pt_comm_world(const PtComm* c) { return c ? c->world : 0; }
+
+// The single exchange step.  d_gathered (rank 0 only; may be NULL elsewhere) receives the world buffers of n_floats each,
+// rank-major — the layout pt_untile reads.  Asynchronous on hip_stream.
+int pt_gather_tiles(PtComm* c, const float* d_tiles, int64_t n_floats, float* d_gathered, void* hip_stream)
+{
+    if (!c || !d_tiles || n_floats < 0 || (c->rank == 0 && !d_gathered)) { pt_set_error("pt_gather_tiles: bad argument"); return PT_ERR_INVALID; }
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (c->world == 1) {
+        if (d_gathered != d_tiles) HIPCHK(hipMemcpyAsync(d_gathered, d_tiles, (size_t)n_floats * 4, hipMemcpyDeviceToDevice, stream));
+        return PT_OK;
+    }
+    Rccl* R = rccl();
+    if (!R || !c->comm) { pt_set_error("pt_gather_tiles: communicator has no RCCL handle"); return PT_ERR_INVALID; }
+    HIPCHK(hipSetDevice(c->device));
+    NCCLCHK(R->Gather(d_tiles, d_gathered, (size_t)n_floats, ncclFloat, 0, c->comm, stream));
+    return PT_OK;
+}
+
+// Gather + de-interleave: rank 0 ends with the row-major W*H*3 frame in d_frame_rgb.  d_gathered is scratch of
+// world * pt_tiles_floats() floats on rank 0 (NULL elsewhere, where d_frame_rgb is ignored too).
+int pt_gather_frame(PtComm* c, const float* d_tiles, const PtCamera* cam, const PtParams* prm, float* d_gathered, float* d_frame_rgb, void* hip_stream)
+{
+    if (!c || !cam || !prm) { pt_set_error("pt_gather_frame: NULL argument"); return PT_ERR_INVALID; }
+    if (prm->world != c->world || prm->rank != c->rank) { pt_set_error("pt_gather_frame: params say rank %d of %d, communicator rank %d of %d", prm->rank, prm->world, c->rank, c->world); return PT_ERR_INVALID; }
+    const int64_t n = pt_tiles_floats(cam, prm);
+    if (n < 0) return PT_ERR_INVALID;
+    int rc = pt_gather_tiles(c, d_tiles, n, d_gathered, hip_stream);
+    if (rc) return rc;
+    if (c->rank == 0) {
+        if (!d_frame_rgb) { pt_set_error("pt_gather_frame: rank 0 needs d_frame_rgb"); return PT_ERR_INVALID; }
+        return pt_untile(d_gathered, cam, c->world, d_frame_rgb, hip_stream);
+    }
+    return PT_OK;
+}
+
+}  // extern "C"

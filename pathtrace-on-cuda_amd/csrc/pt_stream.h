@@ -24,11 +24,10 @@ struct WfCounters {      // one slot per iteration parity (3 rotating slots); ev
     uint32_t nActive, padA[31];
     uint32_t nRays[kRayKinds][32];                 // [kind][0]: rays queued per kind
     uint32_t nSusp, padD[31];
-    uint32_t nNext, padE[31];                      // streams handed from wf_shade0 to wf_shade1 (a new sample starts)
     struct { uint32_t v, pad[31]; } head[16];     // sharded ray-queue heads, one 128-B line each
 };
 constexpr int kWfShards = 16;
-constexpr int kWfSlotBytes = 128 * (3 + kRayKinds + 16);
+constexpr int kWfSlotBytes = 128 * (2 + kRayKinds + 16);
 static_assert(sizeof(WfCounters) == kWfSlotBytes, "counter slot layout");
 
 struct WfBuf {
@@ -49,7 +48,6 @@ struct WfBuf {
     float2* hit[kRayKinds];      // t | primitive index (int bits); prim <= -2: traversal suspended, record -2-prim
     uint32_t* active[2];         // live stream ids, ping-pong
     uint32_t* rq[kRayKinds];     // ray queues (stream ids)
-    uint32_t* next;              // streams that start a new sample in this step (wf_shade0 -> wf_shade1)
     WfCounters* cnt;     // [3]
     float* staging;      // per-pass means, [stream][3]
     int* ovf;            // traversal stack overflow (entries >= kWfLdsStack), [level][thread]
@@ -122,11 +120,9 @@ struct SState {
 // except visibility (include/CudaUtil.cuh:216-373): emission, the NEE sample (its term is parked in st.wb / lightP /
 // cosA / denom until the shadow ray is back), the BSDF sample and the roulette.  Leaves the shadow ray in st.sh* and,
 // unless the path ends here (returns true), the next path ray in st.pathO / pathD.
-// LOBE >= 0: the caller knows the hit's lobe (streams are binned by it); -1: decided here.
 // ---------------------------------------------------------------------------------------
-template <int LOBE>
 PT_DEV bool bounce(const DevScene& sc, const DevParams& prm, int prim, float t, const f3& rorg, const f3& rdir,
-                   SState& st, bool& bRefracted, bool& neeOk)
+                   SState& st, bool& bRefracted, bool& neeOk, bool& needShadow)
 {
     const int Nl = sc.n_lights;
     Surf s;
@@ -134,7 +130,7 @@ PT_DEV bool bounce(const DevScene& sc, const DevParams& prm, int prim, float t, 
     else surf_sphere(sc, prim - sc.n_tris, t, rorg, rdir, s);
     if (sqlen(s.m.emittance) > kEps) st.radiance += st.weight * s.m.emittance;   // :220-224
     const float ior = ior_of(s.m);                                          // :231
-    const int lobe = LOBE >= 0 ? LOBE : lobe_of(s.m);
+    const int lobe = lobe_of(s.m);
     const f3 wo = -rdir;
     // NEE sample (:235-245, SamplePrimitive :38-48)
     const int li = (int)(st.rng.next() % (uint32_t)Nl);
@@ -153,6 +149,22 @@ PT_DEV bool bounce(const DevScene& sc, const DevParams& prm, int prim, float t, 
     st.wb = st.weight * brdfcos;
     st.lightP = lightP;
     st.denom = sqlen(s.p - lightP) * pdfLight;
+    // Dead NEE terms need no shadow ray.  The term ((wb * Le) * cosA) / denom (GetLightColor's result times :271-272) depends on the
+    // shadow ray only through Le, which is 0 or a primitive's emittance (finite and >= 0: checked at upload, DevScene::nee_prune).
+    //  * brdfcos NaN: the reference skips the term (:271), nobody reads the ray;
+    //  * every component of wb an exact zero (the light is below the surface's horizon: eval returns 0), cosA finite and
+    //    0 < denom < inf: wb * Le = +-0 whatever Le is, so the term is +-0, and adding +-0 never changes a radiance (a radiance
+    //    component is never -0: it starts as +0 and only (-0) + (-0) gives -0);
+    //  * cosA exactly 0 with |wb| < 1e30 and 0 < denom < inf: (wb * Le) is finite, times 0 is +-0, same argument.
+    // Everything else — including the NaN-producing corner cases, which must be reproduced — keeps its ray.
+    {
+        const float kInf = __builtin_inff();
+        const bool denomOk = st.denom > 0.f && st.denom < kInf;
+        const bool wbZero = st.wb.x == 0.f && st.wb.y == 0.f && st.wb.z == 0.f;
+        const bool wbSmall = __builtin_fabsf(st.wb.x) < 1e30f && __builtin_fabsf(st.wb.y) < 1e30f && __builtin_fabsf(st.wb.z) < 1e30f;
+        const bool dead = !neeOk || (denomOk && ((wbZero && st.cosA < kInf) || (st.cosA == 0.f && wbSmall)));
+        needShadow = !(dead && sc.nee_prune);
+    }
     // BSDF sample (:283-338)
     const f3 wi = lobe_sample(lobe, s.m, ior, s.fr, wo, st.rng);
     const f3 w1 = lobe_eval(lobe, s.m, ior, s.fr, wo, wi);
@@ -273,125 +285,24 @@ PT_DEV bool shade_step(const DevScene& sc, const DevCamera& cam, const DevParams
             }
         }
         if (go) {
-            const bool terminate = bounce<-1>(sc, prm, prim, t, rorg, rdir, st, bRefracted, neeCur);
-            shCur = true;
+            bool needSh;
+            const bool terminate = bounce(sc, prm, prim, t, rorg, rdir, st, bRefracted, neeCur, needSh);
+            shCur = needSh;
             if (!terminate) { pathCur = true; closing = false; }
-            else { pathCur = false; closing = true; }
+            else {
+                pathCur = false;
+                // A path that ends with no NEE term pending has nothing to wait for.  In round 0 it joins the pixel at once (the older
+                // closed sample was added at the top of this step, so the order of additions is kept) and the next sample can start;
+                // in round 1 an older sample may still sit in slot A, so the new one waits as a current sample without rays and
+                // is added by the next step's "closed one step ago" branch.
+                if (needSh || round == 1) closing = true;
+                else { add_to_pixel(st.radiance); cur = false; closing = false; }
+            }
         }
     }
     st.flags = (cur ? F_CUR : 0u) | (shCur ? F_SHADOW : 0u) | (neeCur ? F_NEEOK : 0u) | (pathCur ? F_PATH : 0u) |
                (shA ? F_SHADOWA : 0u) | (neeA ? F_NEEOKA : 0u) | (bRefracted ? F_REFR : 0u);
     return !cur && !shA && st.toStart == 0;
-}
-
-// ---------------------------------------------------------------------------------------
-// The same step cut in two, for the pipeline's shade kernels (pt_wavefront.hip).  Inside one wave the second hit of a
-// step (the next sample's first bounce) is shaded by the quarter of the lanes whose path has just ended while the
-// others wait, so the pipeline runs it as a second launch over a compacted list instead:
-//   step_first : parts a, b and the current path's hit (round 0).  Returns STEP_DONE (stream finished: write the mean),
-//                STEP_CONT (state complete, st.flags set: store and queue its rays) or STEP_NEXT: a new sample has to
-//                start.  For STEP_NEXT the closed sample has been moved to slot A and st.flags holds only F_SHADOWA /
-//                F_NEEOKA; the caller stores the RNG, counters, flags and pixel and hands the stream to step_next.
-//   step_next  : starts the next sample at the cached camera-ray hit (round 1) and completes the flags.
-// Per stream the order of draws and of float operations is that of shade_step (tests compare the two bit for bit:
-// wf_drain runs shade_step).
-// ---------------------------------------------------------------------------------------
-enum : int { STEP_DONE = 0, STEP_CONT = 1, STEP_NEXT = 2 };
-
-PT_DEV int step_first(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const WfBuf& b, uint32_t sid, SState& st,
-                      float2 hitP, float2 hitS, float2 hitA, float2& h0)
-{
-    const float4* __restrict__ pixPtr = &b.pix[sid];
-    float2* __restrict__ hit0Ptr = &b.hit0[sid];
-    const uint32_t flags = st.flags;
-    bool bRefracted = (flags & F_REFR) != 0;
-    const int primS = (flags & F_SHADOW) ? __float_as_int(hitS.y) : -1;
-    const int primA = (flags & F_SHADOWA) ? __float_as_int(hitA.y) : -1;
-    const float4 emS = tri_emit4(sc, (primS >= 0 && primS < sc.n_tris) ? primS : 0);
-    const float4 emA = tri_emit4(sc, (primA >= 0 && primA < sc.n_tris) ? primA : 0);
-    h0 = hitP;
-    if (!(flags & F_PRIMARY)) h0 = *hit0Ptr;
-
-    auto add_to_pixel = [&](const f3& r) {                                  // pathtracer.cu:79
-        if (!st.pixLoaded) { const float4 pq = *pixPtr; st.pixelColor = f3(pq.x, pq.y, pq.z); st.pixLoaded = true; }
-        st.pixelColor += r;
-    };
-    // ---- a. the older closed sample: its last NEE term, then it joins the pixel ----
-    if (flags & F_SHADOWA) {
-        const float4 ra = b.radA[sid], wa = b.wbA[sid], la = b.lpA[sid], ao = b.ray_o[2][sid], ad = b.ray_d[2][sid];
-        f3 radA(ra.x, ra.y, ra.z);
-        f3 Le(0.f, 0.f, 0.f);
-        if (primA >= 0) {
-            const f3 hp = f3(ao.x, ao.y, ao.z) + hitA.x * f3(ad.x, ad.y, ad.z);
-            if (length(hp - f3(la.x, la.y, la.z)) < kEps) Le = (primA < sc.n_tris) ? f3(emA.x, emA.y, emA.z) : prim_emittance(sc, primA);
-        }
-        if (flags & F_NEEOKA) radA += ((f3(wa.x, wa.y, wa.z) * Le) * wa.w) / ra.w;      // GetLightColor tail + CudaUtil.cuh:271-272
-        add_to_pixel(radA);
-    }
-    // ---- b. pending NEE term of the current sample ----
-    if (flags & F_SHADOW) {
-        f3 Le(0.f, 0.f, 0.f);
-        if (primS >= 0) {
-            const f3 hp = st.shO + hitS.x * st.shD;
-            if (length(hp - st.lightP) < kEps) Le = (primS < sc.n_tris) ? f3(emS.x, emS.y, emS.z) : prim_emittance(sc, primS);
-        }
-        if (flags & F_NEEOK) st.radiance += ((st.wb * Le) * st.cosA) / st.denom;
-    }
-    bool cur = (flags & F_CUR) != 0;
-    bool closing = false, shCur = false, neeCur = false, pathCur = false, shA = false, neeA = false;
-    if (flags & F_PRIMARY) *hit0Ptr = hitP;                                  // the camera ray's hit, shared by every sample
-    else if (!(flags & F_PATH) && cur) { add_to_pixel(st.radiance); cur = false; }   // the current sample closed one step ago
-    // ---- c. round 0: the current path's hit ----
-    if ((flags & F_PATH) && !(flags & F_PRIMARY)) {
-        const int prim = __float_as_int(hitP.y);
-        if (prim < 0) {
-            st.radiance += st.weight * f3(0.1f, 0.1f, 0.1f);                   // CudaUtil.cuh:375-379: the path left the scene
-            add_to_pixel(st.radiance);
-            cur = false;
-        } else {
-            const f3 rorg = st.pathO, rdir = st.pathD;
-            const bool terminate = bounce<-1>(sc, prm, prim, hitP.x, rorg, rdir, st, bRefracted, neeCur);
-            shCur = true;
-            pathCur = !terminate; closing = terminate;
-        }
-    }
-    // ---- d. does a new sample start in this step? ----
-    if ((!cur || closing) && st.toStart > 0) {
-        if (closing) {
-            // the closed sample waits in slot A for its shadow ray; the pixel gets it first thing next step
-            b.radA[sid] = make_float4(st.radiance.x, st.radiance.y, st.radiance.z, st.denom);
-            b.wbA[sid] = make_float4(st.wb.x, st.wb.y, st.wb.z, st.cosA);
-            b.lpA[sid] = make_float4(st.lightP.x, st.lightP.y, st.lightP.z, 0.f);
-            b.ray_o[2][sid] = make_float4(st.shO.x, st.shO.y, st.shO.z, st.shTmax);
-            b.ray_d[2][sid] = make_float4(st.shD.x, st.shD.y, st.shD.z, 0.f);
-            shA = true; neeA = neeCur; shCur = false; neeCur = false;
-        }
-        if (__float_as_int(h0.y) < 0) {
-            // the pixel looks past the scene: every remaining sample is the ambient term (no draws, no rays)
-            do { st.radiance = f3(0.f, 0.f, 0.f); st.radiance += f3(1.f, 1.f, 1.f) * f3(0.1f, 0.1f, 0.1f); add_to_pixel(st.radiance); } while (--st.toStart > 0);
-            cur = false;
-        } else {
-            st.flags = (shA ? F_SHADOWA : 0u) | (neeA ? F_NEEOKA : 0u);
-            return STEP_NEXT;
-        }
-    }
-    st.flags = (cur ? F_CUR : 0u) | (shCur ? F_SHADOW : 0u) | (neeCur ? F_NEEOK : 0u) | (pathCur ? F_PATH : 0u) |
-               (shA ? F_SHADOWA : 0u) | (neeA ? F_NEEOKA : 0u) | (bRefracted ? F_REFR : 0u);
-    return (!cur && !shA && st.toStart == 0) ? STEP_DONE : STEP_CONT;
-}
-
-// Round 1.  `st` carries the RNG, toStart and the partial flags step_first left; everything else of the new sample starts here.
-template <int LOBE>
-PT_DEV void step_next(const DevScene& sc, const DevCamera& cam, const DevParams& prm, SState& st, float2 h0, const f3& dir0)
-{
-    const uint32_t part = st.flags & (F_SHADOWA | F_NEEOKA);
-    st.toStart--;                                                            // pathtracer.cu:77-78: next sample
-    st.weight = f3(1.f, 1.f, 1.f); st.radiance = f3(0.f, 0.f, 0.f);
-    st.depth = 0; st.refractCnt = 0;
-    bool bRefracted = false, neeCur = false;
-    const f3 rorg(cam.pos[0], cam.pos[1], cam.pos[2]);
-    const bool terminate = bounce<LOBE>(sc, prm, __float_as_int(h0.y), h0.x, rorg, dir0, st, bRefracted, neeCur);
-    st.flags = F_CUR | F_SHADOW | (neeCur ? F_NEEOK : 0u) | (terminate ? 0u : F_PATH) | part | (bRefracted ? F_REFR : 0u);
 }
 
 PT_DEV void load_state(const WfBuf& b, uint32_t sid, SState& st)

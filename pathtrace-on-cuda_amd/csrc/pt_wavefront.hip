@@ -140,12 +140,13 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
 // closest one.
 // ---------------------------------------------------------------------------------------
 // STAT: a diagnostic build that also counts trips and the lanes they serve (pt_last_counters; PTAMD_TSTAT=1).
-template <bool STAT>
+template <int MODE>      // 0 production, 1 trip counters + timeline (PTAMD_TSTAT=1), 2 timeline only (PTAMD_TSTAT=2)
 __global__ __launch_bounds__(256, TRACE_WAVES)
 void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift, int triTrig, int refillMin,
               int topWant, unsigned long long* stat, int statLaunch)
 {
-    const unsigned long long stT0 = STAT ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz
+    constexpr bool STAT = MODE == 1, timeline = MODE != 0;
+    const unsigned long long stT0 = timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz
     unsigned long long stTExh = 0;
     unsigned long long stNodeTrips = 0, stNodeLanes = 0, stTriTrips = 0, stTriLanes = 0, stRefills = 0, stRefillLanes = 0, stNoRayLanes = 0, stRays = 0;
     __shared__ int lds_stack[4][kWfLdsStack * 64];
@@ -212,7 +213,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     if (start < hi - lo) { chunkPos = lo + start; chunkEnd = (hi - lo - start > want) ? chunkPos + want : hi; seenLeft = hi - lo - start; break; }
                     seenLeft = 0xffffffffu;
                     shard = (shard + 1) % kWfShards;
-                    if (++shardsTried >= kWfShards) { exhausted = true; if (STAT) stTExh = __builtin_amdgcn_s_memrealtime(); break; }
+                    if (++shardsTried >= kWfShards) { exhausted = true; if (timeline) stTExh = __builtin_amdgcn_s_memrealtime(); break; }
                 }
             }
             if (!exhausted) {
@@ -263,7 +264,6 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
             }
         }
         if (__ballot(hasRay) == 0ull) { if (exhausted) break; else continue; }
-
         if (hasRay) {
             // Only one code path runs per trip: a node step or ONE triangle test per lane (the vote is below).
             // (The classic while-while shape made 64 lanes wait for the slowest lane to reach a leaf every
@@ -313,8 +313,11 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 uint4 n0, n1, n2; uint2 n3;
 #if TRACE_TOP_NODES > 0
                 if (cur < topN) {
-                    const uint4* np = lds_top + cur * kTopStride;
-                    n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = *(const uint2*)(np + 3);
+                    // explicit LDS reads: left to itself the compiler merges the two address spaces into flat_load instructions,
+                    // which cost the whole kernel 18 % (every node fetch then waits on both counters and the ray origin spills)
+                    const uint32_t la = (uint32_t)(uintptr_t)(lds_top + cur * kTopStride);
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b64 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3) : "v"(la) : "memory");
                 } else
 #endif
                 {
@@ -403,21 +406,21 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
             }
         }
     }
-    if (STAT) {
+    if (timeline) {
         // per-lane ray count -> wave total
         unsigned long long r = stRays;
-        for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
+        if (STAT) for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
         if (lane == 0) {
-            atomicAdd(&stat[0], stNodeTrips); atomicAdd(&stat[1], stNodeLanes); atomicAdd(&stat[2], stTriTrips); atomicAdd(&stat[3], stTriLanes);
+            if (STAT) { atomicAdd(&stat[0], stNodeTrips); atomicAdd(&stat[1], stNodeLanes); atomicAdd(&stat[2], stTriTrips); atomicAdd(&stat[3], stTriLanes); }
             // launch timeline (100 MHz ticks): earliest wave start, earliest "queue empty", latest wave exit
             unsigned long long* tl = stat + 8 + 3 * (size_t)statLaunch;
             const unsigned long long tEnd = __builtin_amdgcn_s_memrealtime();
             atomicMax(&tl[0], ~stT0); if (stTExh) atomicMax(&tl[1], ~stTExh); atomicMax(&tl[2], tEnd);
-            // distribution of wave exit times over the launch, all launches pooled: 16 bins of 1/16 of ... (absolute: 32 us bins)
+            // distribution of wave exit times over the launch, all launches pooled (absolute: 32 us bins)
             unsigned long long* hist = stat + 8 + 3 * 2700;
             const unsigned long long dtk = (tEnd - stT0) / 3200ull;      // 32 us bins (100 MHz ticks)
             atomicAdd(&hist[dtk < 31 ? dtk : 31], 1ull);
-            atomicAdd(&stat[4], stRefills); atomicAdd(&stat[5], stRefillLanes); atomicAdd(&stat[6], stNoRayLanes); atomicAdd(&stat[7], r);
+            if (STAT) { atomicAdd(&stat[4], stRefills); atomicAdd(&stat[5], stRefillLanes); atomicAdd(&stat[6], stNoRayLanes); atomicAdd(&stat[7], r); }
         }
     }
 }
@@ -462,98 +465,6 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
     uint32_t* const c[kLists] = {&b.cnt[slotOut].nActive, &b.cnt[slotOut].nRays[0][0], &b.cnt[slotOut].nRays[1][0], &b.cnt[slotOut].nRays[2][0]};
     uint32_t* const l[kLists] = {b.active[listIn ^ 1], b.rq[0], b.rq[1], b.rq[2]};
     block_append<kLists>(e, sid, c, l);
-}
-
-// ---------------------------------------------------------------------------------------
-// wf_shade0 / wf_shade1: the same step as two launches (pt_stream.h: step_first / step_next).  wf_shade0 runs one thread
-// per live stream: NEE terms whose shadow rays are back, the current path's hit.  Streams that start a new sample in
-// this step (their path has just ended: about a quarter of them) are compacted into the `next` list and wf_shade1
-// shades the cached camera-ray hit for them in full waves; inside wf_shade that second hit ran at a quarter of the
-// lanes while the rest of the wave waited (profiles/r01_pmc_traffic.json: 45 % lane utilisation).
-// ---------------------------------------------------------------------------------------
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 256, WAVES)
-void wf_shade0(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, int slotOut, int slotClear, int listIn)
-{
-    const uint32_t nIn = b.cnt[slotIn].nActive;
-    if (blockIdx.x == 0) for (int k = threadIdx.x; k < kWfSlotBytes / 4; k += blockDim.x) ((uint32_t*)&b.cnt[slotClear])[k] = 0;
-    if ((uint32_t)blockIdx.x * blockDim.x >= nIn) return;
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool have = idx < nIn;
-    bool alive = false, emit[kRayKinds] = {false, false, false}, toNext = false;
-    uint32_t sid = 0;
-    if (have) {
-        sid = b.active[listIn][idx];
-        SState st;
-        const float2 hitP = b.hit[0][sid], hitS = b.hit[1][sid], hitA = b.hit[2][sid];      // same fetch level as the state
-        load_state(b, sid, st);
-        // a ray of this stream is still being traversed (time-sliced): wait one iteration
-        const int pendP = (st.flags & F_PATH) ? __float_as_int(hitP.y) : -1, pendS = (st.flags & F_SHADOW) ? __float_as_int(hitS.y) : -1;
-        const int pendA = (st.flags & F_SHADOWA) ? __float_as_int(hitA.y) : -1;
-        if (pendP <= -2 || pendS <= -2 || pendA <= -2) {
-            alive = true; emit[0] = pendP <= -2; emit[1] = pendS <= -2; emit[2] = pendA <= -2;
-        } else {
-            float2 h0;
-            const int r = step_first(sc, cam, prm, b, sid, st, hitP, hitS, hitA, h0);
-            if (r == STEP_DONE) {
-                write_mean(b, prm, sid, st);
-            } else if (r == STEP_CONT) {
-                const uint32_t nf = st.flags;
-                store_state(b, sid, st);
-                alive = true;
-                emit[0] = (nf & F_PATH) != 0; emit[1] = (nf & F_SHADOW) != 0; emit[2] = (nf & F_SHADOWA) != 0;
-            } else {
-                // A new sample starts: wf_shade1 finishes the step.  The stream and its rays are queued HERE, so that every list
-                // keeps the order of the live list (neighbouring streams stay neighbours: their state loads coalesce and their
-                // rays walk the same nodes — appending them from wf_shade1 instead shuffled the lists and made both kernels
-                // 1.5-2x slower).  The path ray is queued before it is known to exist; wf_shade1 leaves a null ray if not.
-                b.rng0[sid] = make_uint4(st.rng.x0, st.rng.x1, st.rng.x2, st.rng.x3);
-                b.rng1[sid] = make_uint4(st.rng.x4, st.rng.d, ((uint32_t)st.toStart << 16), st.flags);
-                if (st.pixLoaded) b.pix[sid] = make_float4(st.pixelColor.x, st.pixelColor.y, st.pixelColor.z, 0.f);
-                toNext = true; alive = true;
-                emit[0] = true; emit[1] = true; emit[2] = (st.flags & F_SHADOWA) != 0;
-            }
-        }
-    }
-    const bool e[kLists + 1] = {alive, emit[0], emit[1], emit[2], toNext};
-    uint32_t* const c[kLists + 1] = {&b.cnt[slotOut].nActive, &b.cnt[slotOut].nRays[0][0], &b.cnt[slotOut].nRays[1][0], &b.cnt[slotOut].nRays[2][0], &b.cnt[slotOut].nNext};
-    uint32_t* const l[kLists + 1] = {b.active[listIn ^ 1], b.rq[0], b.rq[1], b.rq[2], b.next};
-    block_append<kLists + 1>(e, sid, c, l);
-}
-
-template <int LOBE>
-__global__ __launch_bounds__(256)
-void wf_shade1(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotOut)
-{
-    const uint32_t nIn = b.cnt[slotOut].nNext;
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nIn) return;
-    const uint32_t sid = b.next[idx];
-    const uint4 r0 = b.rng0[sid], r1 = b.rng1[sid];
-    const float4 d0 = b.dir0[sid];
-    const float2 h0 = b.hit0[sid];
-    SState st;
-    st.rng.x0 = r0.x; st.rng.x1 = r0.y; st.rng.x2 = r0.z; st.rng.x3 = r0.w; st.rng.x4 = r1.x; st.rng.d = r1.y;
-    st.toStart = (int)(r1.z >> 16); st.flags = r1.w;
-    step_next<LOBE>(sc, cam, prm, st, h0, f3(d0.x, d0.y, d0.z));
-    const uint32_t nf = st.flags;
-    b.rng0[sid] = make_uint4(st.rng.x0, st.rng.x1, st.rng.x2, st.rng.x3);
-    b.rng1[sid] = make_uint4(st.rng.x4, st.rng.d, ((uint32_t)st.toStart << 16) | ((uint32_t)st.depth << 8) | (uint32_t)st.refractCnt, nf);
-    b.weight[sid] = make_float4(st.weight.x, st.weight.y, st.weight.z, st.cosA);
-    b.rad[sid] = make_float4(st.radiance.x, st.radiance.y, st.radiance.z, st.denom);
-    b.ray_o[1][sid] = make_float4(st.shO.x, st.shO.y, st.shO.z, st.shTmax);
-    b.ray_d[1][sid] = make_float4(st.shD.x, st.shD.y, st.shD.z, 0.f);
-    b.wb[sid] = make_float4(st.wb.x, st.wb.y, st.wb.z, 0.f);
-    b.lp[sid] = make_float4(st.lightP.x, st.lightP.y, st.lightP.z, 0.f);
-    if (nf & F_PATH) {
-        b.ray_o[0][sid] = make_float4(st.pathO.x, st.pathO.y, st.pathO.z, 999999.f);
-        b.ray_d[0][sid] = make_float4(st.pathD.x, st.pathD.y, st.pathD.z, 0.f);
-    } else {
-        // the sample ended at its first hit: the path ray wf_shade0 queued for it is a null ray (t_max < 0: nothing can be hit,
-        // one node step), and without F_PATH nobody reads its result
-        b.ray_o[0][sid] = make_float4(0.f, 0.f, 0.f, -1.f);
-        b.ray_d[0][sid] = make_float4(0.57735026f, 0.57735026f, 0.57735026f, 0.f);
-    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -608,7 +519,7 @@ static size_t cohort_bytes(size_t nStreams, int traceBlocks)
     b += n16 * 16 * 11;                       // 11 float4 state arrays
     b += n16 * 16 * 2 * ptd::kRayKinds;       // ray_o/ray_d per kind
     b += n16 * 8 * (ptd::kRayKinds + 1);      // hits per kind + the cached camera-ray hit
-    b += n16 * 4 * (3 + ptd::kRayKinds);      // active x2, one ray queue per kind, the next-sample list
+    b += n16 * 4 * (2 + ptd::kRayKinds);      // active x2, one ray queue per kind
     b += 3 * ptd::kWfSlotBytes; // counters
     b += (size_t)traceBlocks * 256 * ptd::kWfOvfLevels * 4;
     b += 2 * ((nStreams / 4 + 1024) * ptd::kSuspInts * 4 + 16);
@@ -651,7 +562,6 @@ static void carve(char* p, size_t nStreams, int traceBlocks, ptd::WfBuf& b)
     b.hit0 = (float2*)take(n16 * 8);
     for (int k = 0; k < 2; k++) b.active[k] = (uint32_t*)take(n16 * 4);
     for (int k = 0; k < ptd::kRayKinds; k++) b.rq[k] = (uint32_t*)take(n16 * 4);
-    b.next = (uint32_t*)take(n16 * 4);
     b.cnt = (ptd::WfCounters*)take(3 * ptd::kWfSlotBytes);
     b.ovf = (int*)take((size_t)traceBlocks * 256 * ptd::kWfOvfLevels * 4);
     b.suspCap = (uint32_t)(nStreams / 4 + 1024);
@@ -698,8 +608,8 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     static const int triTrig = getenv("PTAMD_TT") ? atoi(getenv("PTAMD_TT")) : 64;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
     static const int topNodes = getenv("PTAMD_TOP") ? atoi(getenv("PTAMD_TOP")) : kTopNodes;      // quad nodes staged in LDS (0 = none)
-    static const bool splitShade = getenv("PTAMD_SPLIT") ? atoi(getenv("PTAMD_SPLIT")) != 0 : false;     // wf_shade0 + wf_shade1 instead of wf_shade
     unsigned long long* const traceStat = g_traceStat;
+    static const bool traceStatFull = getenv("PTAMD_TSTAT") && atoi(getenv("PTAMD_TSTAT")) == 1;      // 1: trip counters too (slower build); 2: timeline only
     int it = 0;
     int poll = 16;
     // streams only ever retire, so the live count of the last poll bounds every later one: the shade grid
@@ -710,20 +620,14 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
             const bool timed = trace_ev && it < trace_ev_pairs;
             if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
-            if (traceStat) hipLaunchKernelGGL(wf_trace<true>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
-            else hipLaunchKernelGGL(wf_trace<false>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, 0);
+            if (traceStat && traceStatFull) hipLaunchKernelGGL(wf_trace<1>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
+            else if (traceStat) hipLaunchKernelGGL(wf_trace<2>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
+            else hipLaunchKernelGGL(wf_trace<0>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, 0);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
             const dim3 sg((liveBound + shadeThreads - 1) / shadeThreads), sb(shadeThreads);
-            if (!splitShade) {
-                if (shadeWaves == 2) hipLaunchKernelGGL(wf_shade<2>, sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
-                else if (shadeWaves == 3) hipLaunchKernelGGL(wf_shade<3>, sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
-                else hipLaunchKernelGGL(wf_shade<4>, sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
-            } else {
-                if (shadeWaves == 2) hipLaunchKernelGGL(wf_shade0<2>, sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
-                else if (shadeWaves == 3) hipLaunchKernelGGL(wf_shade0<3>, sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
-                else hipLaunchKernelGGL(wf_shade0<4>, sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
-                hipLaunchKernelGGL(wf_shade1<-1>, dim3((liveBound + 255) / 256), dim3(256), 0, stream, *sc, *cam, prm, b, sOut);
-            }
+            if (shadeWaves == 2) hipLaunchKernelGGL(wf_shade<2>, sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
+            else if (shadeWaves == 3) hipLaunchKernelGGL(wf_shade<3>, sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
+            else hipLaunchKernelGGL(wf_shade<4>, sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(h_cnt, &b.cnt[it % 3].nActive, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;

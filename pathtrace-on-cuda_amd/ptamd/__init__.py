@@ -67,6 +67,14 @@ API = [
     ("pt_render", C.c_int, [_P, C.POINTER(PtCamera), C.POINTER(PtParams), _P]),
     ("pt_last_render_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
     ("pt_render_timings", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    ("pt_comm_unique_id", C.c_int, [_P]),
+    ("pt_comm_create", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    ("pt_comm_create_from_file", C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    ("pt_comm_destroy", None, [_P]),
+    ("pt_comm_rank", C.c_int32, [_P]),
+    ("pt_comm_world", C.c_int32, [_P]),
+    ("pt_gather_tiles", C.c_int, [_P, _P, C.c_int64, _P, _P]),
+    ("pt_gather_frame", C.c_int, [_P, _P, C.POINTER(PtCamera), C.POINTER(PtParams), _P, _P, _P]),
     ("pt_tonemap_u8", C.c_int, [_P, C.c_int64, C.c_int32, _P]),
     ("pt_convert_u8", C.c_int, [_P, C.c_int64, _P]),
     ("pt_write_png", C.c_int, [C.c_char_p, _P, C.c_int32, C.c_int32, C.c_int32]),
@@ -328,6 +336,50 @@ def work_bytes(cam, prm):
 
 def untile(d_gathered_ptr, cam, world, d_frame_ptr, stream_ptr=0):
     _check(lib().pt_untile(C.c_void_p(d_gathered_ptr), C.byref(cam), world, C.c_void_p(d_frame_ptr), C.c_void_p(stream_ptr)), "pt_untile")
+
+
+class Comm:
+    """PtComm: the C-ABI's communicator for the single gather (RCCL under it when world > 1)."""
+
+    def __init__(self, rank=0, world=1, device=0, unique_id=None, id_file=None, timeout_s=60):
+        self._h = C.c_void_p()
+        if id_file is not None:
+            _check(lib().pt_comm_create_from_file(id_file.encode(), rank, world, device, timeout_s, C.byref(self._h)), "pt_comm_create_from_file")
+        else:
+            buf = (C.c_uint8 * 128)(*(unique_id or bytes(128)))
+            _check(lib().pt_comm_create(buf, rank, world, device, C.byref(self._h)), "pt_comm_create")
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        _check(lib().pt_comm_unique_id(buf), "pt_comm_unique_id")
+        return bytes(buf)
+
+    @property
+    def rank(self):
+        return lib().pt_comm_rank(self._h)
+
+    @property
+    def world(self):
+        return lib().pt_comm_world(self._h)
+
+    def gather_tiles(self, d_tiles_ptr, n_floats, d_gathered_ptr, stream_ptr=0):
+        _check(lib().pt_gather_tiles(self._h, C.c_void_p(d_tiles_ptr), n_floats, C.c_void_p(d_gathered_ptr), C.c_void_p(stream_ptr)), "pt_gather_tiles")
+
+    def gather_frame(self, d_tiles_ptr, cam, prm, d_gathered_ptr, d_frame_ptr, stream_ptr=0):
+        _check(lib().pt_gather_frame(self._h, C.c_void_p(d_tiles_ptr), C.byref(cam), C.byref(prm), C.c_void_p(d_gathered_ptr),
+                                     C.c_void_p(d_frame_ptr), C.c_void_p(stream_ptr)), "pt_gather_frame")
+
+    def close(self):
+        if self._h:
+            lib().pt_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def dbg_bxdf(lobe, in28, device=0):

@@ -191,6 +191,31 @@ def test_tile_split_is_bitwise_invariant():
         assert np.array_equal(bits(gathered.cpu().numpy().reshape(-1, 3)[idx].reshape(H, W, 3)), bits(base))
 
 
+def test_c_abi_gather_frame_world1():
+    """The C-ABI's exchange step (pt_comm_create / pt_gather_frame) with a world of one: a device copy + pt_untile, bit for bit
+    the frame pt_render returns.  (world > 1 runs ncclGather and needs one GPU per rank: unmeasured on this one-GPU box.)"""
+    import torch
+    from ptamd.dist import TileRenderer
+    sc = ptamd.Scene.from_prims(ptamd.gen_scene(1, 16))
+    W, H = 100, 52
+    cam = ptamd.make_camera(W, H)
+    prm = ptamd.default_params(passes=2, spp_per_pass=4)
+    base = sc.render(cam, prm)
+    dev = torch.device("cuda:0")
+    tr = TileRenderer(sc, cam, prm, dev)
+    tiles = tr.render()
+    gathered = torch.empty_like(tiles)
+    frame = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    comm = ptamd.Comm(rank=0, world=1, device=0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    comm.gather_frame(tiles.data_ptr(), cam, prm, gathered.data_ptr(), frame.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(frame.cpu().numpy()), bits(base))
+    with pytest.raises(ptamd.PtError):          # params of another split than the communicator's
+        comm.gather_frame(tiles.data_ptr(), cam, ptamd.default_params(passes=2, spp_per_pass=4, rank=0, world=2), gathered.data_ptr(), frame.data_ptr(), stream)
+    comm.close()
+
+
 def test_full_frame_1080p_window_parity_and_split():
     """At BASELINE's frame size (1920x1080, stand-in scene, 69,576 triangles): a pixel window
     of the GPU frame equals the oracle's render of that window (same full-frame seeds), and

@@ -124,3 +124,16 @@ def test_scene_gen_counts():
     assert ptamd.gen_scene(0).shape == (12, 84)
     assert ptamd.gen_scene(1, 187).shape[0] == 12 + 69564
     assert ptamd.gen_scene(2, 187).shape[0] == 12 + 4 * 69564
+
+
+def test_comm_single_rank_and_argument_checks(tmp_path):
+    """pt_comm_* on the host: a world of one needs neither RCCL nor a GPU; bad geometry is rejected; a rank that never
+    gets the id file times out with PT_ERR_IO instead of hanging."""
+    c = ptamd.Comm(rank=0, world=1)
+    assert (c.rank, c.world) == (0, 1)
+    c.close()
+    for rank, world in ((1, 1), (-1, 2), (2, 2), (0, 0)):
+        with pytest.raises(ptamd.PtError):
+            ptamd.Comm(rank=rank, world=world, unique_id=bytes(128))
+    with pytest.raises(ptamd.PtError, match="timed out"):
+        ptamd.Comm(rank=1, world=2, id_file=str(tmp_path / "never_written.id"), timeout_s=0)
