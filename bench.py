@@ -22,8 +22,8 @@ Also on the JSON line:
                  VALU one: achieved = lane-operations per second = (active-lane VALU instructions per sample, from the
                  PMC passes committed under profiles/, SQ_THREAD_CYCLES_VALU) x samples per launch / the kernel's
                  average launch duration, MEASURED LIVE here with HIP event pairs on the launch stream; peak = 256 CUs
-                 x 4 SIMDs x 16 lanes/clk x 2.4 GHz (one wave64 VALU instruction per SIMD per 4 clocks — measured by
-                 pt_dbg_valu_rate, reported beside it).  traffic = HBM-side bytes per launch from the L2's fabric
+                 x 4 SIMDs x 32 lanes/clk x 2.4 GHz (the fp32 vector rate; pt_dbg_valu_rate measures what the chip really
+                 issues and is reported beside it).  traffic = HBM-side bytes per launch from the L2's fabric
                  request counters (same PMC passes, per sample x samples per launch); hbm_frac prices them against
                  8 TB/s.  The figure SURVEY.md 8(d) defines — algorithmic bytes of the REFERENCE's traversal divided by
                  this kernel's time — is reported separately as vs_reference_algorithm (it is a speed-up over a
@@ -45,9 +45,12 @@ sys.path.insert(0, os.path.join(ROOT, "pathtrace-on-cuda_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-# VALU peak in lane-operations per second: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz (a wave64 instruction holds its
-# SIMD for 4 clocks; pt_dbg_valu_rate measures exactly that for v_fma_f32 / v_max3_f32 / v_cvt / integer adds).
-VALU_PEAK_GLOPS = 256 * 4 * 16 * 2.4
+# VALU peak in lane-operations per second: 256 CUs x 4 SIMDs x 32 lanes per clock x 2.4 GHz = the 157 TFLOP/s fp32 vector
+# rate / 2.  Only plain 2-operand / fma / integer-add instructions issue at that rate (one wave64 instruction per SIMD per 2 clocks,
+# and only with >= 2 waves per SIMD); v_max3 / v_cvt_f32_ubyte / packed and fp64 instructions take 4 clocks (all measured by
+# pt_dbg_valu_rate: gpurun_out -> profiles/r02_valu_probe.json).  The traversal kernel's mix is about half of each, so its
+# practical ceiling is ~0.7 of this peak; the fraction is quoted against the hard one.
+VALU_PEAK_GLOPS = 256 * 4 * 32 * 2.4
 LAT_LON = 187
 
 # BASELINE.json configs[1..4] -> passes x spp_per_pass as SURVEY.md 8(d) maps them

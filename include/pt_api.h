@@ -9,7 +9,7 @@
  * Every function returns PT_OK (0) or a negative PtStatus and records a message that
  * pt_last_error() returns (thread-local).  The reference's own convention for GPU errors
  * — print to stderr, reset the device, exit(99) (include/CudaUtil.cuh:28-36) — is kept by
- * the C++ adaptor `PathTracer::Render` (pathtrace-on-cuda_amd/host/pathtracer.cpp), not
+ * the C++ adaptor `PathTracer::Render` (pathtrace-on-cuda_amd/host/ref_surface.cpp), not
  * imposed on C callers.
  */
 #ifndef PT_API_H
@@ -143,12 +143,19 @@ PT_API int64_t pt_scene_device_bytes(const PtScene* s);
 /* ----------------------------------------------------------------------------------
  * (a3-a11) Render.  Replaces the StartRender launch loop (srcs/pathtracer.cu:236-246).
  *
- * pt_render_tiles: device-resident, asynchronous on `hip_stream` (a hipStream_t, may be
- *   NULL).  Writes this rank's tiles, tile-major, into d_tiles:
+ * pt_render_tiles: device-resident; all GPU work is enqueued on `hip_stream` (a hipStream_t, may be NULL) and ordered after
+ *   whatever the caller enqueued there before.  Writes this rank's tiles, tile-major, into d_tiles:
  *     d_tiles[((lt * 64) + (ty*8+tx)) * 3 + c],  lt = local tile index (global tile
  *     t = lt*world + rank), float32, size pt_tiles_floats().  Value = sum over the call's
  *     passes of the per-pass mean radiance (the reference's `image[offset] += mean`,
  *     pathtracer.cu:81), starting from 0.  d_work is scratch of pt_work_bytes() bytes.
+ *   BLOCKING in the default render path (mode 1, the queue-driven pipeline): the number of bounce iterations is
+ *   data-dependent, so the call polls the live-stream count (a 4-byte read-back + hipStreamSynchronize every 16-64
+ *   iterations) and returns only when the render has drained; on return only the final pass-sum kernel may still be
+ *   running on `hip_stream`.  As blocking as the reference's own Render (cudaDeviceSynchronize after every launch,
+ *   srcs/pathtracer.cu:236-246).  A caller that drives several scenes or GPUs from one process gives each its own host
+ *   thread.  Mode 0 (pt_set_mode, the one-kernel state machine) is fully asynchronous.  One render at a time per PtScene
+ *   (the scene owns the pinned poll word, events and counters the render uses); different scenes are independent.
  * pt_untile: scatter gathered tile buffers (rank-major: world buffers of
  *   pt_tiles_floats() each) into a row-major W*H*3 frame, on the device.
  * pt_render: convenience, whole frame (world=1) into a host buffer, synchronous;
@@ -229,6 +236,13 @@ PT_API int  pt_dbg_raycast(PtScene* s, const float* rays8, int32_t n, float* out
 PT_API int  pt_dbg_bxdf(int32_t device, int32_t lobe, const float* in28, int32_t n, float* out12);
 PT_API int  pt_dbg_rng(int32_t device, uint64_t seed, int32_t n, uint32_t* raw_out, float* uniform_out);
 PT_API int  pt_dbg_math(int32_t device, const float* in, int32_t n, float* out8);
+/* StartRender's prologue + GetPixelDirection (srcs/pathtracer.cu:33-40,70-74) for n rows (px, py, pass) of int32:
+ * out8 = u1 u2 | dir.xyz (after the Ray constructor's second normalisation) | the RNG's next uniform draw | 0 0. */
+PT_API int  pt_dbg_pixel_dir(int32_t device, const PtCamera* cam, const int32_t* pxpypass, int32_t n, float* out8);
+/* One NEE sample + its visibility (include/CudaUtil.cuh:235-245, SamplePrimitive :38-48, GetLightColor :150-166) per row.
+ * in5 = surface point p.xyz | RNG seed low, high (uint32 bits); out12 = light index (int bits) | sampled point xyz | pdfLight |
+ * cosA | shadow ray t_max | closest-hit primitive of the shadow ray (int bits) | GetLightColor rgb | the RNG's next draw. */
+PT_API int  pt_dbg_nee(PtScene* s, const float* in5, int32_t n, float* out12);
 /* Measurement aid: stream triad a = b + s*c over three float4 arrays of `bytes_per_array`
  * each, `iters` times; *gb_per_s = bytes moved (2 reads + 1 write per element) / time of the timed launches. */
 PT_API int  pt_dbg_triad(int32_t device, int64_t bytes_per_array, int32_t iters, double* gb_per_s);

@@ -89,7 +89,9 @@ int  o_render(void* scene, const OCamera* cam, const OParams* prm, float* accum_
               int64_t* counters, int nthreads);
 
 void o_tonemap(const float* raw_rgb, int n_pixels, int sample_cnt, unsigned char* rgb8);
-void o_u8(const float* v, int n, unsigned char* out);      /* ConverToUint8, include/image.h:5-8 */
+void o_u8(const float* v, int n, unsigned char* out);
+void o_pixel_dir(const OCamera* cam, const int* pxpypass, int n, float* out8);   /* StartRender prologue + GetPixelDirection, srcs/pathtracer.cu:33-40,70-74 */
+void o_nee(void* scene, const float* in5, int n, float* out12);                  /* NEE sample + GetLightColor, include/CudaUtil.cuh:38-48,150-166,235-245 */      /* ConverToUint8, include/image.h:5-8 */
 
 /* BxDF known-answer table.  lobe: 0 gltfpbr, 1 reflective, 2 refractive, 3 pure_refractive.
  * in  (28 f/row): normal(3) tangent(3) bitangent(3) frontface | albedo(3) specular(3)

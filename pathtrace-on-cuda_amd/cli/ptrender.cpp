@@ -16,6 +16,7 @@ static void usage()
         "                [--glass-sphere] [--width W] [--height H] [--passes N] [--spp N] [--depth N]\n"
         "                [--lat-lon N] [--device D] [--no-progressive] [--raw FILE]\n"
         "Writes temp.png (per pass) and result.png in the current directory, like PathTracer::Render.\n"
+        "--raw FILE: also writes the float accumulation buffer (W*H*3 float32) there after every pass (viewer hook).\n"
         "Defaults: scene cornell, 1920x1080, 8 passes x 64 spp, depth 8.\n";
 }
 
@@ -69,10 +70,9 @@ int main(int argc, char** argv)
 
     PathTracer tracer;
     tracer.params.passes = passes; tracer.params.spp_per_pass = spp; tracer.params.max_bounce = depth;
-    tracer.device = device; tracer.progressive = progressive;
+    tracer.device = device; tracer.progressive = progressive; tracer.raw_path = rawPath;
     tracer.Render(camera, &bvh);
     const double samples = (double)W * H * passes * spp;
     std::cout << "{\"msamples_per_s_kernel\": " << samples / (tracer.last_render_ms * 1e-3) / 1e6 << ", \"kernel_ms\": " << tracer.last_render_ms << "}" << std::endl;
-    (void)rawPath;
     return 0;
 }

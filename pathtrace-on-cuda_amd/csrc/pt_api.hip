@@ -26,13 +26,14 @@ hipError_t ptk_dbg_raycast(const ptd::DevScene*, const float*, int, float*, int*
 hipError_t ptk_dbg_bxdf(int, const float*, int, float*, hipStream_t);
 hipError_t ptk_dbg_rng(unsigned long long, int, uint32_t*, float*, hipStream_t);
 hipError_t ptk_dbg_math(const float*, int, float*, hipStream_t);
+hipError_t ptk_dbg_pixel_dir(const ptd::DevCamera*, const int*, int, float*, hipStream_t);
+hipError_t ptk_dbg_nee(const ptd::DevScene*, const float*, int, float*, hipStream_t);
 size_t ptk_wf_work_bytes(size_t nUnits, int traceBlocks);
 int ptk_wf_cohorts(size_t nUnits);
 const float* ptk_wf_staging(void* work);
-void ptk_wf_set_stat(void*);
 int ptk_wf_stack_capacity(void);
 hipError_t ptk_wf_render(int, const ptd::DevScene*, const ptd::DevCamera*, const ptd::DevParams*, void*, int, uint32_t*, hipStream_t, hipStream_t*,
-                         hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t*, int*, hipEvent_t*, int, int*, int);
+                         hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t*, int*, hipEvent_t*, int, int*, int, void*);
 }
 
 void pt_set_error(const char* fmt, ...);   // pt_host.cpp
@@ -61,7 +62,7 @@ struct PtScene {
     int max_depth = 0;
     int num_cus = 256;
     bool count_next = false;
-    int mode = 1;            // 1 = wavefront pipeline (default), 0 = one-kernel state machine, 2 = persistent workgroup-local pipeline
+    int mode = 1;            // 1 = wavefront pipeline (default), 0 = one-kernel state machine
     uint32_t* h_poll = nullptr;   // pinned, for the pipeline's live-stream count
     int last_iters = 0;
     int drain_below = 0;         // hand the last streams to wf_drain once this few are live (0 = never; measured slower than the tail it replaces)
@@ -93,16 +94,20 @@ static int with_buffers(int device, const void* in, size_t in_bytes, void* out, 
 {
     HIPCHK(hipSetDevice(device));
     void *d_in = nullptr, *d_out = nullptr, *d_out2 = nullptr;
-    HIPCHK(hipMalloc(&d_in, in_bytes ? in_bytes : 16));
-    HIPCHK(hipMalloc(&d_out, out_bytes ? out_bytes : 16));
-    HIPCHK(hipMalloc(&d_out2, out2_bytes ? out2_bytes : 16));
-    if (in_bytes) HIPCHK(hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice));
-    HIPCHK(launch(d_in, d_out, d_out2));
-    HIPCHK(hipDeviceSynchronize());
-    if (out_bytes) HIPCHK(hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost));
-    if (out2_bytes) HIPCHK(hipMemcpy(out2, d_out2, out2_bytes, hipMemcpyDeviceToHost));
-    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_out2);
-    return PT_OK;
+    auto body = [&]() -> int {
+        HIPCHK(hipMalloc(&d_in, in_bytes ? in_bytes : 16));
+        HIPCHK(hipMalloc(&d_out, out_bytes ? out_bytes : 16));
+        HIPCHK(hipMalloc(&d_out2, out2_bytes ? out2_bytes : 16));
+        if (in_bytes) HIPCHK(hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice));
+        HIPCHK(launch(d_in, d_out, d_out2));
+        HIPCHK(hipDeviceSynchronize());
+        if (out_bytes) HIPCHK(hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost));
+        if (out2_bytes) HIPCHK(hipMemcpy(out2, d_out2, out2_bytes, hipMemcpyDeviceToHost));
+        return PT_OK;
+    };
+    const int rc = body();
+    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_out2);      // on every path (hipFree(nullptr) is a no-op)
+    return rc;
 }
 
 
@@ -223,19 +228,24 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
         pt_scene_destroy(sc);
         return rc;
     }
-    HIPCHK(hipMalloc((void**)&sc->d_unit_counter, 64));
-    HIPCHK(hipMalloc(&sc->d_counters, kCounterBytes));      // 8 work counters (+ the diagnostic launch timeline of wf_trace)
-    HIPCHK(hipMemset(sc->d_counters, 0, kCounterBytes));
-    for (int i = 0; i < PtScene::kEvRing; i++) { HIPCHK(hipEventCreate(&sc->ev[i][0])); HIPCHK(hipEventCreate(&sc->ev[i][1])); }
-    HIPCHK(hipHostMalloc((void**)&sc->h_poll, 4 * 64, hipHostMallocDefault));
-    for (int i = 0; i < 3; i++) { HIPCHK(hipStreamCreateWithFlags(&sc->xstreams[i], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&sc->ev_join[i], hipEventDisableTiming)); }
-    HIPCHK(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
+    // from here on every failure destroys the half-built scene (geometry already uploaded, events, streams)
+    auto finish = [&]() -> int {
+        HIPCHK(hipMalloc((void**)&sc->d_unit_counter, 64));
+        HIPCHK(hipMalloc(&sc->d_counters, kCounterBytes));      // 8 work counters (+ the diagnostic launch timeline of wf_trace)
+        HIPCHK(hipMemset(sc->d_counters, 0, kCounterBytes));
+        for (int i = 0; i < PtScene::kEvRing; i++) { HIPCHK(hipEventCreate(&sc->ev[i][0])); HIPCHK(hipEventCreate(&sc->ev[i][1])); }
+        HIPCHK(hipHostMalloc((void**)&sc->h_poll, 4 * 64, hipHostMallocDefault));
+        for (int i = 0; i < 3; i++) { HIPCHK(hipStreamCreateWithFlags(&sc->xstreams[i], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&sc->ev_join[i], hipEventDisableTiming)); }
+        HIPCHK(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        sc->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        return PT_OK;
+    };
+    if ((rc = finish()) != PT_OK) { pt_scene_destroy(sc); return rc; }
     // environment overrides of the per-scene defaults (the same settings have C-ABI setters: pt_set_mode, pt_set_drain_threshold)
     if (const char* m = getenv("PTAMD_MODE")) { const int v = atoi(m); if (v >= 0 && v <= 1) sc->mode = v; }
     if (const char* m = getenv("PTAMD_DRAIN")) sc->drain_below = atoi(m);
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device));
-    sc->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     sc->dev.nodes = (const float4*)sc->d_nodes; sc->dev.quad = (const uint4*)sc->d_quad; sc->dev.tri = (const float4*)sc->d_tri;
     sc->dev.leafbox = (const float4*)sc->d_leafbox; sc->dev.surf = (const float4*)sc->d_surf;
     sc->dev.lights = (const float4*)sc->d_lights; sc->dev.spheres = (const float4*)sc->d_spheres;
@@ -265,7 +275,7 @@ int64_t pt_scene_device_bytes(const PtScene* s) { return s ? s->bytes : 0; }
 
 // persistent grid of the traversal kernel: 256 CUs x 7 blocks of 4 waves = 7 waves/SIMD, what its 72 VGPRs allow
 // (PTAMD_TB overrides, tuning only; measured: 1536 blocks -3 %, 1024 blocks -22 %)
-static const int kTraceBlocks = getenv("PTAMD_TB") ? atoi(getenv("PTAMD_TB")) : 1792;
+static const int kTraceBlocks = (getenv("PTAMD_TB") && atoi(getenv("PTAMD_TB")) >= 1) ? (atoi(getenv("PTAMD_TB")) > 16384 ? 16384 : atoi(getenv("PTAMD_TB"))) : 1792;
 
 // ---- geometry of the tile split --------------------------------------------------------
 static int fill_params(const PtCamera* cam, const PtParams* prm, ptd::DevParams& d)
@@ -296,6 +306,17 @@ static int fill_params(const PtCamera* cam, const PtParams* prm, ptd::DevParams&
     return PT_OK;
 }
 
+// srcs/pathtracer.cu:193-198 and :35-36 — the per-launch camera constants, tan/atan2 as correctly rounded float functions
+static void fill_camera(const PtCamera* cam, ptd::DevCamera& c)
+{
+    memcpy(c.pos, cam->pos, 12); memcpy(c.forward, cam->forward, 12); memcpy(c.up, cam->up, 12); memcpy(c.right, cam->right, 12);
+    c.W = cam->W; c.H = cam->H;
+    const float fovy = cam->fovy_deg * 0.01745329251994329576923690768489f;                 // glm::radians
+    const float fovx = 2.f * (float)std::atan2((double)((float)std::tan((double)(fovy * 0.5f)) * cam->aspect), 1.0);
+    c.tan_half_fovx = (float)std::tan((double)(fovx * 0.5f));
+    c.tan_half_fovy = (float)std::tan((double)(fovy * 0.5f));
+}
+
 int64_t pt_tiles_floats(const PtCamera* cam, const PtParams* prm)
 {
     ptd::DevParams d;
@@ -322,13 +343,7 @@ int pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm, float*
     int rc = fill_params(cam, prm, d);
     if (rc) return rc;
     ptd::DevCamera c;
-    memcpy(c.pos, cam->pos, 12); memcpy(c.forward, cam->forward, 12); memcpy(c.up, cam->up, 12); memcpy(c.right, cam->right, 12);
-    c.W = cam->W; c.H = cam->H;
-    // srcs/pathtracer.cu:197-198 and :35-36 — correctly rounded float tan/atan2
-    const float fovy = cam->fovy_deg * 0.01745329251994329576923690768489f;                 // glm::radians
-    const float fovx = 2.f * (float)std::atan2((double)((float)std::tan((double)(fovy * 0.5f)) * cam->aspect), 1.0);
-    c.tan_half_fovx = (float)std::tan((double)(fovx * 0.5f));
-    c.tan_half_fovy = (float)std::tan((double)(fovy * 0.5f));
+    fill_camera(cam, c);
 
     hipStream_t stream = (hipStream_t)hip_stream;
     HIPCHK(hipSetDevice(s->device));
@@ -343,10 +358,10 @@ int pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm, float*
         // diagnostic (PTAMD_TSTAT=1): wf_trace counts its trips and the lanes they serve; read with pt_last_counters
         static const bool kTraceStat = getenv("PTAMD_TSTAT") && atoi(getenv("PTAMD_TSTAT")) != 0;
         if (kTraceStat) HIPCHK(hipMemsetAsync(s->d_counters, 0, kCounterBytes, stream));
-        ptk_wf_set_stat(kTraceStat ? s->d_counters : nullptr);
         HIPCHK(ptk_wf_render(s->device, &s->dev, &c, &d, d_work, kTraceBlocks, s->h_poll, stream, s->xstreams,
                              s->ev[slot][0], s->ev[slot][1], s->ev_fork, s->ev_join, &iters,
-                             s->trace_ev.empty() ? nullptr : s->trace_ev.data(), (int)s->trace_ev.size() / 2, s->trace_ev_used, s->drain_below));
+                             s->trace_ev.empty() ? nullptr : s->trace_ev.data(), (int)s->trace_ev.size() / 2, s->trace_ev_used, s->drain_below,
+                             kTraceStat ? s->d_counters : nullptr));
         s->last_iters = iters;
         s->ev_count++;
         HIPCHK(ptk_sum_passes(ptk_wf_staging(d_work), d.passes, perPass, d_tiles, stream));
@@ -386,15 +401,16 @@ int pt_render(PtScene* s, const PtCamera* cam, const PtParams* prm, float* h_acc
     if (nt < 0 || wb < 0) return PT_ERR_INVALID;
     HIPCHK(hipSetDevice(s->device));
     float *d_tiles = nullptr, *d_frame = nullptr; void* d_work = nullptr;
-    HIPCHK(hipMalloc((void**)&d_tiles, (size_t)nt * 4));
-    HIPCHK(hipMalloc(&d_work, (size_t)wb));
-    HIPCHK(hipMalloc((void**)&d_frame, (size_t)cam->W * cam->H * 12));
-    int rc = pt_render_tiles(s, cam, &p, d_tiles, d_work, nullptr);
-    if (!rc) rc = pt_untile(d_tiles, cam, 1, d_frame, nullptr);
-    if (!rc) {
-        hipError_t e = hipMemcpy(h_accum_rgb, d_frame, (size_t)cam->W * cam->H * 12, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { pt_set_error("hipMemcpy D2H: %s", hipGetErrorString(e)); rc = PT_ERR_DEVICE; }
-    }
+    auto body = [&]() -> int {
+        HIPCHK(hipMalloc((void**)&d_tiles, (size_t)nt * 4));
+        HIPCHK(hipMalloc(&d_work, (size_t)wb));
+        HIPCHK(hipMalloc((void**)&d_frame, (size_t)cam->W * cam->H * 12));
+        int r = pt_render_tiles(s, cam, &p, d_tiles, d_work, nullptr);
+        if (!r) r = pt_untile(d_tiles, cam, 1, d_frame, nullptr);
+        if (!r) HIPCHK(hipMemcpy(h_accum_rgb, d_frame, (size_t)cam->W * cam->H * 12, hipMemcpyDeviceToHost));
+        return r;
+    };
+    const int rc = body();
     (void)hipFree(d_tiles); (void)hipFree(d_work); (void)hipFree(d_frame);
     return rc;
 }
@@ -539,6 +555,22 @@ int pt_dbg_triad(int32_t device, int64_t bytes_per_array, int32_t iters, double*
     if (b) (void)hipFree(b);
     if (c) (void)hipFree(c);
     return rc;
+}
+
+int pt_dbg_pixel_dir(int32_t device, const PtCamera* cam, const int32_t* pxpypass, int32_t n, float* out8)
+{
+    if (!cam || !pxpypass || !out8 || n < 0 || cam->W < 2 || cam->H < 2) { pt_set_error("pt_dbg_pixel_dir: bad argument"); return PT_ERR_INVALID; }
+    ptd::DevCamera c;
+    fill_camera(cam, c);
+    return with_buffers(device, pxpypass, (size_t)n * 12, out8, (size_t)n * 32, nullptr, 0,
+                        [&](void* i, void* o, void*) { return ptk_dbg_pixel_dir(&c, (const int*)i, n, (float*)o, nullptr); });
+}
+int pt_dbg_nee(PtScene* s, const float* in5, int32_t n, float* out12)
+{
+    if (!s || !in5 || !out12 || n < 0) { pt_set_error("pt_dbg_nee: bad argument"); return PT_ERR_INVALID; }
+    if (s->n_lights < 1) { pt_set_error("pt_dbg_nee: scene has no light"); return PT_ERR_NO_LIGHT; }
+    return with_buffers(s->device, in5, (size_t)n * 20, out12, (size_t)n * 48, nullptr, 0,
+                        [&](void* i, void* o, void*) { return ptk_dbg_nee(&s->dev, (const float*)i, n, (float*)o, nullptr); });
 }
 
 int pt_dbg_math(int32_t device, const float* in, int32_t n, float* out8)

@@ -97,4 +97,60 @@ PT_DEV void make_surf(const DevScene& sc, int prim, float t, const f3& org, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Next-event estimation pieces and the pixel direction, shared by the render kernels and by the parity hooks
+// (pt_dbg_nee / pt_dbg_pixel_dir) that compare them with the oracle row by row.
+// ---------------------------------------------------------------------------------------
+struct NeeSample {
+    int li;              // light picked: curand(s) % Nl, CudaUtil.cuh:235
+    f3 lightP;           // SamplePrimitive's point, :38-48
+    f3 toL, wl;          // lightP - p and its normalisation (the shadow ray's direction, Ray ctor CudaRay.cuh:12)
+    float pdfLight;      // (1 / area) / Nl, :236
+    float cosA;          // max(dot(light normal, normalize(p - lightP)), 0), :240-241
+};
+PT_DEV NeeSample nee_sample(const DevScene& sc, Rng& rng, const f3& p)
+{
+    const int Nl = sc.n_lights;
+    NeeSample n;
+    n.li = (int)(rng.next() % (uint32_t)Nl);
+    const float4 l0 = sc.lights[4 * n.li], l1 = sc.lights[4 * n.li + 1], l2 = sc.lights[4 * n.li + 2], l3 = sc.lights[4 * n.li + 3];
+    const f3 LV0(l0.x, l0.y, l0.z), LV1(l0.w, l1.x, l1.y), LV2(l1.z, l1.w, l2.x), LN(l2.y, l2.z, l2.w);
+    const float r1u = __builtin_sqrtf(rng.uniform());
+    const float r2u = rng.uniform();
+    n.lightP = (1.f - r1u) * LV0 + (r1u * (1.f - r2u)) * LV1 + (r1u * r2u) * LV2;
+    n.pdfLight = (1.f / l3.x) / ((float)Nl);
+    n.toL = n.lightP - p;
+    n.wl = normalize(n.toL);
+    const float ca = dot(LN, normalize(p - n.lightP));
+    n.cosA = (ca < 0.f) ? 0.f : ca;
+    return n;
+}
+
+// GetLightColor's verdict (CudaUtil.cuh:157-165) from the shadow ray's closest hit (t, prim): the hit primitive's emittance (passed in:
+// the shade kernel fetches it ahead of time) if the hit point lies within EPS of the sampled light point, else black.
+PT_DEV f3 nee_light_color(const f3& shO, const f3& shD, const f3& lightP, float t, int prim, const f3& primEmittance)
+{
+    f3 Le(0.f, 0.f, 0.f);
+    if (prim >= 0) {
+        const f3 hp = shO + t * shD;
+        if (length(hp - lightP) < kEps) Le = primEmittance;
+    }
+    return Le;
+}
+
+// GetPixelDirection (srcs/pathtracer.cu:33-40) with the two jitter draws of StartRender (:72-73), then the Ray constructor's second
+// normalisation (CudaRay.cuh:12).
+PT_DEV f3 pixel_direction(const DevCamera& cam, int px, int py, Rng& rng, float& u1, float& u2)
+{
+    const f3 camF(cam.forward[0], cam.forward[1], cam.forward[2]);
+    const f3 camU(cam.up[0], cam.up[1], cam.up[2]);
+    const f3 camR(cam.right[0], cam.right[1], cam.right[2]);
+    u1 = rng.uniform();
+    u2 = rng.uniform();
+    const f3 offR = ((2.f * (((float)px + u1) / (float)(cam.W - 1) - 0.5f)) * cam.tan_half_fovx) * camR;
+    const f3 offU = ((-2.f * (((float)py + u2) / (float)(cam.H - 1) - 0.5f)) * cam.tan_half_fovy) * camU;
+    const f3 direction = normalize(camF + offR + offU);
+    return normalize(direction);
+}
+
 }  // namespace ptd

@@ -20,6 +20,17 @@ enum : uint32_t {
 };
 constexpr int kRayKinds = 3;     // 0 path, 1 shadow of the current sample, 2 shadow of the older closed sample
 
+// Shadow rays only decide whether the closest hit is the sampled light point (GetLightColor, CudaUtil.cuh:150-166: visible iff
+// |hit.p - P| < EPS with t_max = |P - p| + 1).  Any hit at t < (t_max - 1) - margin proves that the closest hit lies at least
+// margin - EPS in front of P, so the traversal may stop there: margin = 5e-4, or 64 ulps of the largest coordinate involved where
+// that is more (coordinates in the thousands: the rounding of org + t*dir must not eat the reference's EPS = 1e-4).  Computed where the
+// ray is emitted (the traversal kernel is the one short of issue slots) and carried in ray_d.w.
+PT_DEV float shadow_stop_t(const f3& o, float tmax)
+{
+    const float mag = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fmaxf(__builtin_fabsf(o.z), tmax));
+    return (tmax - 1.0f) - __builtin_fmaxf(5e-4f, mag * 7.6293945e-6f);
+}
+
 struct WfCounters {      // one slot per iteration parity (3 rotating slots); every hot word on its own 128-B line
     uint32_t nActive, padA[31];
     uint32_t nRays[kRayKinds][32];                 // [kind][0]: rays queued per kind
@@ -44,7 +55,7 @@ struct WfBuf {
     float4* wbA;         //                      weight*brdfcos | cosA
     float4* lpA;         //                      light point
     float4* ray_o[kRayKinds];    // org.xyz | tmax
-    float4* ray_d[kRayKinds];    // dir.xyz
+    float4* ray_d[kRayKinds];    // dir.xyz | shadow rays: the t below which any hit ends the traversal (shadow_stop_t); path rays: -inf
     float2* hit[kRayKinds];      // t | primitive index (int bits); prim <= -2: traversal suspended, record -2-prim
     uint32_t* active[2];         // live stream ids, ping-pong
     uint32_t* rq[kRayKinds];     // ray queues (stream ids)
@@ -59,18 +70,11 @@ struct WfBuf {
 // jittered camera direction and queues the camera ray, whose hit all samples of the pass share.
 PT_DEV void init_stream(const DevCamera& cam, const DevParams& prm, const WfBuf& b, uint32_t slot, int px, int py, int pass)
 {
-    const f3 camF(cam.forward[0], cam.forward[1], cam.forward[2]);
-    const f3 camU(cam.up[0], cam.up[1], cam.up[2]);
-    const f3 camR(cam.right[0], cam.right[1], cam.right[2]);
     const int offset = py * cam.W + px;
     Rng rng;
     rng.init((uint64_t)(int64_t)(offset + pass * cam.W * cam.H));
-    const float u1 = rng.uniform();
-    const float u2 = rng.uniform();
-    const f3 offR = ((2.f * (((float)px + u1) / (float)(cam.W - 1) - 0.5f)) * cam.tan_half_fovx) * camR;
-    const f3 offU = ((-2.f * (((float)py + u2) / (float)(cam.H - 1) - 0.5f)) * cam.tan_half_fovy) * camU;
-    const f3 direction = normalize(camF + offR + offU);      // GetPixelDirection, pathtracer.cu:33-40
-    const f3 d0 = normalize(direction);                      // Ray ctor normalises again, CudaRay.cuh:12
+    float u1, u2;
+    const f3 d0 = pixel_direction(cam, px, py, rng, u1, u2);      // GetPixelDirection + Ray ctor (pt_shade.h)
     b.rng0[slot] = make_uint4(rng.x0, rng.x1, rng.x2, rng.x3);
     b.rng1[slot] = make_uint4(rng.x4, rng.d, ((uint32_t)prm.spp_per_pass << 16), F_PATH | F_PRIMARY);
     b.weight[slot] = make_float4(1.f, 1.f, 1.f, 0.f);
@@ -78,7 +82,7 @@ PT_DEV void init_stream(const DevCamera& cam, const DevParams& prm, const WfBuf&
     b.pix[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     b.dir0[slot] = make_float4(d0.x, d0.y, d0.z, 0.f);
     b.ray_o[0][slot] = make_float4(cam.pos[0], cam.pos[1], cam.pos[2], 999999.f);
-    b.ray_d[0][slot] = make_float4(d0.x, d0.y, d0.z, 0.f);
+    b.ray_d[0][slot] = make_float4(d0.x, d0.y, d0.z, -__builtin_inff());
     for (int k = 0; k < kRayKinds; k++) b.hit[k][slot] = make_float2(0.f, __int_as_float(-1));
 }
 
@@ -124,7 +128,6 @@ struct SState {
 PT_DEV bool bounce(const DevScene& sc, const DevParams& prm, int prim, float t, const f3& rorg, const f3& rdir,
                    SState& st, bool& bRefracted, bool& neeOk, bool& needShadow)
 {
-    const int Nl = sc.n_lights;
     Surf s;
     if (prim < sc.n_tris) { SurfRec rec; load_surf(sc, prim, rec); surf_from_rec(rec, t, rorg, rdir, s); }
     else surf_sphere(sc, prim - sc.n_tris, t, rorg, rdir, s);
@@ -133,17 +136,10 @@ PT_DEV bool bounce(const DevScene& sc, const DevParams& prm, int prim, float t, 
     const int lobe = lobe_of(s.m);
     const f3 wo = -rdir;
     // NEE sample (:235-245, SamplePrimitive :38-48)
-    const int li = (int)(st.rng.next() % (uint32_t)Nl);
-    const float4 l0 = sc.lights[4 * li], l1 = sc.lights[4 * li + 1], l2 = sc.lights[4 * li + 2], l3 = sc.lights[4 * li + 3];
-    const f3 LV0(l0.x, l0.y, l0.z), LV1(l0.w, l1.x, l1.y), LV2(l1.z, l1.w, l2.x), LN(l2.y, l2.z, l2.w);
-    const float r1u = __builtin_sqrtf(st.rng.uniform());
-    const float r2u = st.rng.uniform();
-    const f3 lightP = (1.f - r1u) * LV0 + (r1u * (1.f - r2u)) * LV1 + (r1u * r2u) * LV2;
-    const float pdfLight = (1.f / l3.x) / ((float)Nl);
-    const f3 toL = lightP - s.p;
-    const f3 wl = normalize(toL);
-    const float ca = dot(LN, normalize(s.p - lightP));
-    st.cosA = (ca < 0.f) ? 0.f : ca;
+    const NeeSample ns = nee_sample(sc, st.rng, s.p);
+    const f3 lightP = ns.lightP, toL = ns.toL, wl = ns.wl;
+    const float pdfLight = ns.pdfLight;
+    st.cosA = ns.cosA;
     const f3 brdfcos = lobe_eval(lobe, s.m, ior, s.fr, wo, wl);
     neeOk = !anynan(brdfcos);
     st.wb = st.weight * brdfcos;
@@ -221,21 +217,15 @@ PT_DEV bool shade_step(const DevScene& sc, const DevCamera& cam, const DevParams
     if (flags & F_SHADOWA) {
         const float4 ra = b.radA[sid], wa = b.wbA[sid], la = b.lpA[sid], ao = b.ray_o[2][sid], ad = b.ray_d[2][sid];
         f3 radA(ra.x, ra.y, ra.z);
-        f3 Le(0.f, 0.f, 0.f);
-        if (primA >= 0) {
-            const f3 hp = f3(ao.x, ao.y, ao.z) + hitA.x * f3(ad.x, ad.y, ad.z);
-            if (length(hp - f3(la.x, la.y, la.z)) < kEps) Le = (primA < sc.n_tris) ? f3(emA.x, emA.y, emA.z) : prim_emittance(sc, primA);
-        }
+        const f3 Le = nee_light_color(f3(ao.x, ao.y, ao.z), f3(ad.x, ad.y, ad.z), f3(la.x, la.y, la.z), hitA.x, primA,
+                                      (primA < sc.n_tris) ? f3(emA.x, emA.y, emA.z) : prim_emittance(sc, primA < 0 ? 0 : primA));
         if (flags & F_NEEOKA) radA += ((f3(wa.x, wa.y, wa.z) * Le) * wa.w) / ra.w;      // GetLightColor tail + CudaUtil.cuh:271-272
         add_to_pixel(radA);
     }
     // ---- b. pending NEE term of the current sample ----
     if (flags & F_SHADOW) {
-        f3 Le(0.f, 0.f, 0.f);
-        if (primS >= 0) {
-            const f3 hp = st.shO + hitS.x * st.shD;
-            if (length(hp - st.lightP) < kEps) Le = (primS < sc.n_tris) ? f3(emS.x, emS.y, emS.z) : prim_emittance(sc, primS);
-        }
+        const f3 Le = nee_light_color(st.shO, st.shD, st.lightP, hitS.x, primS,
+                                      (primS < sc.n_tris) ? f3(emS.x, emS.y, emS.z) : prim_emittance(sc, primS < 0 ? 0 : primS));
         if (flags & F_NEEOK) st.radiance += ((st.wb * Le) * st.cosA) / st.denom;
     }
     bool cur = (flags & F_CUR) != 0;       // a current sample exists
@@ -267,7 +257,7 @@ PT_DEV bool shade_step(const DevScene& sc, const DevCamera& cam, const DevParams
                     b.wbA[sid] = make_float4(st.wb.x, st.wb.y, st.wb.z, st.cosA);
                     b.lpA[sid] = make_float4(st.lightP.x, st.lightP.y, st.lightP.z, 0.f);
                     b.ray_o[2][sid] = make_float4(st.shO.x, st.shO.y, st.shO.z, st.shTmax);
-                    b.ray_d[2][sid] = make_float4(st.shD.x, st.shD.y, st.shD.z, 0.f);
+                    b.ray_d[2][sid] = make_float4(st.shD.x, st.shD.y, st.shD.z, shadow_stop_t(st.shO, st.shTmax));
                     shA = true; neeA = neeCur; shCur = false; neeCur = false; closing = false;
                 }
                 prim = __float_as_int(h0.y); t = h0.x;
@@ -341,13 +331,13 @@ PT_DEV void store_state(const WfBuf& b, uint32_t slot, const SState& st)
     if (st.pixLoaded) b.pix[slot] = make_float4(st.pixelColor.x, st.pixelColor.y, st.pixelColor.z, 0.f);
     if (nf & F_SHADOW) {
         b.ray_o[1][slot] = make_float4(st.shO.x, st.shO.y, st.shO.z, st.shTmax);
-        b.ray_d[1][slot] = make_float4(st.shD.x, st.shD.y, st.shD.z, 0.f);
+        b.ray_d[1][slot] = make_float4(st.shD.x, st.shD.y, st.shD.z, shadow_stop_t(st.shO, st.shTmax));
         b.wb[slot] = make_float4(st.wb.x, st.wb.y, st.wb.z, 0.f);
         b.lp[slot] = make_float4(st.lightP.x, st.lightP.y, st.lightP.z, 0.f);
     }
     if (nf & F_PATH) {
         b.ray_o[0][slot] = make_float4(st.pathO.x, st.pathO.y, st.pathO.z, 999999.f);
-        b.ray_d[0][slot] = make_float4(st.pathD.x, st.pathD.y, st.pathD.z, 0.f);
+        b.ray_d[0][slot] = make_float4(st.pathD.x, st.pathD.y, st.pathD.z, -__builtin_inff());
     }
 }
 

@@ -7,7 +7,7 @@
 // in HBM as SoA float4 arrays; each iteration advances every live stream by one step:
 //
 //   wf_trace  closest hits of all pending path rays and visibility of all pending NEE shadow
-//             rays (one queue index space): lean kernel, 8 waves/SIMD, lanes refill from the queue
+//             rays (one queue index space): lean kernel, 7 waves/SIMD, lanes refill from the queue
 //   wf_shade  one step of every live stream (pt_stream.h): apply the NEE terms whose shadow rays are back,
 //             shade the path hit — and, when that path ends, the first hit of the next sample too
 //             (the camera ray's hit is cached) — emit the shadow and path rays, or retire the stream
@@ -43,6 +43,7 @@ constexpr int kWfOvfLevels = 48;     // further levels spill to global memory (n
 constexpr int kWfChunk = 128;        // most ray ids a wave takes from a queue shard per atomic (measured optimum 116-229)
 constexpr int kWfRefill = 24;        // refill lanes once this many are idle (measured: 8..16 -2 %, 32 -0.4 %)
 constexpr int kDone = (int)0x80000000;
+constexpr uint32_t kShardBlock = 2048;   // queue indices per block of the shard interleave (a power of two)
 // wf_trace's waves per SIMD.  7 (72 VGPRs) rather than 8 (64): the two-triangle leaf test needs the room, and
 // the kernel is bound by VALU issue, not by latency hiding (measured: 8 waves with 9 spilled registers and 6 waves
 // with none are both slower).
@@ -201,8 +202,17 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 // single word saturates near 88 returning atomics per microsecond, which throttled
                 // launches of a few million rays).  A wave drains its home shard, then helps the next.
                 for (;;) {
-                    const uint32_t lo = (uint32_t)(((unsigned long long)n * (unsigned)shard) / kWfShards);
-                    const uint32_t hi = (uint32_t)(((unsigned long long)n * (unsigned)(shard + 1)) / kWfShards);
+                    // A shard owns every 16th block of kShardBlock queue indices (block b -> shard b % 16), so all shards walk the index
+                    // space front to back together: path rays are started first and the (shorter, any-hit) shadow rays last, which
+                    // is what is still in flight when the queue runs dry.  chunkPos / chunkEnd are shard-local positions.
+#ifdef PT_SHARD_CONTIG      // A/B build: a shard owns one contiguous sixteenth of the index space
+                    const uint32_t cLo = (uint32_t)(((unsigned long long)n * (unsigned)shard) / kWfShards);
+                    const uint32_t cnt = (uint32_t)(((unsigned long long)n * (unsigned)(shard + 1)) / kWfShards) - cLo;
+#else
+                    const uint32_t rounds = n / (kShardBlock * kWfShards), rem = n % (kShardBlock * kWfShards);
+                    const uint32_t part = rem > (uint32_t)shard * kShardBlock ? rem - (uint32_t)shard * kShardBlock : 0u;
+                    const uint32_t cnt = rounds * kShardBlock + (part < kShardBlock ? part : kShardBlock);      // indices this shard owns
+#endif
                     // guided self-scheduling: the chunk shrinks with what this wave last saw left in the shard, so the
                     // last rays of a launch are spread over many waves instead of queuing behind one
                     uint32_t want = seenLeft >> guideShift;
@@ -210,7 +220,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     uint32_t start = 0;
                     if (lane == 0) start = atomicAdd(&b.cnt[slot].head[shard].v, want);
                     start = __builtin_amdgcn_readfirstlane(start);
-                    if (start < hi - lo) { chunkPos = lo + start; chunkEnd = (hi - lo - start > want) ? chunkPos + want : hi; seenLeft = hi - lo - start; break; }
+                    if (start < cnt) { chunkPos = start; chunkEnd = (cnt - start > want) ? start + want : cnt; seenLeft = cnt - start; break; }
                     seenLeft = 0xffffffffu;
                     shard = (shard + 1) % kWfShards;
                     if (++shardsTried >= kWfShards) { exhausted = true; if (timeline) stTExh = __builtin_amdgcn_s_memrealtime(); break; }
@@ -223,8 +233,14 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 if (!hasRay) {
                     const uint32_t r = (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
                     if (r < take) {
-                        const uint32_t q = chunkPos + r;
+                        const uint32_t j = chunkPos + r;      // shard-local -> queue index
+#ifdef PT_SHARD_CONTIG
+                        const uint32_t q = (uint32_t)(((unsigned long long)n * (unsigned)shard) / kWfShards) + j;
+#else
+                        const uint32_t q = ((j / kShardBlock) * kWfShards + (uint32_t)shard) * kShardBlock + (j % kShardBlock);
+#endif
                         kind = q < nPath ? 0 : (q < nKind1 ? 1 : 2);
+                        // the per-kind arrays lie back to back at a stride of n16 elements (WfBuf): one base pointer each
                         sid = kind == 0 ? b.rq[0][q] : (kind == 1 ? b.rq[1][q - nPath] : b.rq[2][q - nKind1]);
                         const float4 o = (kind == 0 ? b.ray_o[0] : (kind == 1 ? b.ray_o[1] : b.ray_o[2]))[sid];
                         const float4 d = (kind == 0 ? b.ray_d[0] : (kind == 1 ? b.ray_d[1] : b.ray_d[2]))[sid];
@@ -241,7 +257,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                             inv.z = (__builtin_fabsf(inv.z) <= 1e30f) ? inv.z : __builtin_copysignf(1e30f, dir.z);
                             cscale = 1.0000019f;
                         }
-                        stopBelow = kind != 0 ? (o.w - 1.0f) - 5e-4f : -__builtin_inff();
+                        stopBelow = kind != 0 ? d.w : -__builtin_inff();      // shadow rays: any hit below this t ends the traversal (pt_stream.h: shadow_stop_t)
                         steps = 0;
                         const float2 prev = (kind == 0 ? b.hit[0] : (kind == 1 ? b.hit[1] : b.hit[2]))[sid];
                         const int pp = __float_as_int(prev.y);
@@ -501,6 +517,47 @@ void wf_drain(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
     write_mean(b, prm, sid, st);
 }
 
+// ---------------------------------------------------------------------------------------
+// Parity hooks for the integrator's sub-functions (include/pt_api.h: pt_dbg_pixel_dir, pt_dbg_nee): the SAME device
+// functions the render kernels call (pt_shade.h), run on rows of inputs so that tests can compare them with the oracle
+// one function at a time.
+// ---------------------------------------------------------------------------------------
+__global__ void dbg_pixel_dir(DevCamera cam, const int* __restrict__ pxpypass, int n, float* __restrict__ out8)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int px = pxpypass[3 * i], py = pxpypass[3 * i + 1], pass = pxpypass[3 * i + 2];
+    Rng rng;
+    rng.init((uint64_t)(int64_t)(py * cam.W + px + pass * cam.W * cam.H));      // srcs/pathtracer.cu:70-71
+    float u1, u2;
+    const f3 d = pixel_direction(cam, px, py, rng, u1, u2);
+    float* o = out8 + (size_t)i * 8;
+    o[0] = u1; o[1] = u2; o[2] = d.x; o[3] = d.y; o[4] = d.z; o[5] = rng.uniform(); o[6] = 0.f; o[7] = 0.f;      // o[5]: the next draw (RNG position)
+}
+
+// in5: surface point p.xyz | seed lo | seed hi (uint32 bits).  out12: light index | lightP.xyz | pdfLight | cosA | shadow-ray t_max |
+// closest-hit primitive of the shadow ray (int bits) | Le.xyz (GetLightColor) | next uniform draw.
+__global__ __launch_bounds__(kBlockThreads)
+void dbg_nee(DevScene sc, const float* __restrict__ in5, int n, float* __restrict__ out12)
+{
+    __shared__ int lds_stack[kWavesPerBlock][kStackDepth * 64];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int* stack = &lds_stack[threadIdx.x >> 6][threadIdx.x & 63];
+    if (i >= n) return;
+    const float* r = in5 + (size_t)i * 5;
+    const f3 p(r[0], r[1], r[2]);
+    Rng rng;
+    rng.init(((uint64_t)__float_as_uint(r[4]) << 32) | (uint64_t)__float_as_uint(r[3]));
+    const NeeSample ns = nee_sample(sc, rng, p);
+    const float tmax = length(ns.toL) + 1.0f;                               // GetLightColor, CudaUtil.cuh:152-157
+    float t; TraceStats ts{0, 0, 0};
+    const int prim = trace_closest<false>(sc, p, ns.wl, tmax, stack, t, ts);
+    const f3 Le = nee_light_color(p, ns.wl, ns.lightP, t, prim, prim_emittance(sc, prim < 0 ? 0 : prim));
+    float* o = out12 + (size_t)i * 12;
+    o[0] = __int_as_float(ns.li); o[1] = ns.lightP.x; o[2] = ns.lightP.y; o[3] = ns.lightP.z; o[4] = ns.pdfLight; o[5] = ns.cosA;
+    o[6] = tmax; o[7] = __int_as_float(prim); o[8] = Le.x; o[9] = Le.y; o[10] = Le.z; o[11] = rng.uniform();
+}
+
 }  // namespace ptd
 
 // ---------------------------------------------------------------------------------------
@@ -570,15 +627,11 @@ static void carve(char* p, size_t nStreams, int traceBlocks, ptd::WfBuf& b)
 
 const float* ptk_wf_staging(void* work) { return (const float*)work; }
 
-// diagnostic trip counters of wf_trace (8 x u64 in device memory), or null: set per render by pt_api.hip
-static unsigned long long* g_traceStat = nullptr;
-void ptk_wf_set_stat(void* p) { g_traceStat = (unsigned long long*)p; }
-
 // One cohort's pipeline on its own stream.  Blocks the calling host thread until the cohort has
 // drained (it polls the live-stream count every 16..64 iterations).
 static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::DevCamera* cam, ptd::DevParams prm,
                              ptd::WfBuf b, int traceBlocks, uint32_t* h_cnt, hipStream_t stream,
-                             hipEvent_t* trace_ev, int trace_ev_pairs, int* trace_ev_used, int drainBelow, int* iters_out)
+                             hipEvent_t* trace_ev, int trace_ev_pairs, int* trace_ev_used, int drainBelow, int* iters_out, unsigned long long* traceStat)
 {
     using namespace ptd;
     hipError_t e;
@@ -608,7 +661,6 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     static const int triTrig = getenv("PTAMD_TT") ? atoi(getenv("PTAMD_TT")) : 64;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
     static const int topNodes = getenv("PTAMD_TOP") ? atoi(getenv("PTAMD_TOP")) : kTopNodes;      // quad nodes staged in LDS (0 = none)
-    unsigned long long* const traceStat = g_traceStat;
     static const bool traceStatFull = getenv("PTAMD_TSTAT") && atoi(getenv("PTAMD_TSTAT")) == 1;      // 1: trip counters too (slower build); 2: timeline only
     int it = 0;
     int poll = 16;
@@ -658,7 +710,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
 hipError_t ptk_wf_render(int device, const ptd::DevScene* sc, const ptd::DevCamera* cam, const ptd::DevParams* prm,
                          void* work, int traceBlocks, uint32_t* h_cnt, hipStream_t stream, hipStream_t* xstreams,
                          hipEvent_t ev_begin, hipEvent_t ev_end, hipEvent_t ev_fork, hipEvent_t* ev_join, int* iters_out,
-                         hipEvent_t* trace_ev, int trace_ev_pairs, int* trace_ev_used, int drainBelow)
+                         hipEvent_t* trace_ev, int trace_ev_pairs, int* trace_ev_used, int drainBelow, void* traceStat)
 {
     using namespace ptd;
     const size_t nUnits = (size_t)prm->n_units;
@@ -685,7 +737,7 @@ hipError_t ptk_wf_render(int device, const ptd::DevScene* sc, const ptd::DevCame
         hipEvent_t* tev = trace_ev ? trace_ev + (size_t)2 * evPer * c : nullptr;
         int* used = trace_ev_used ? &trace_ev_used[c] : nullptr;
         if (cp.n_units == 0) { if (used) *used = 0; continue; }
-        auto job = [=, &rc, &iters]() { rc[(size_t)c] = run_cohort(device, sc, cam, cp, b, traceBlocks, h_cnt + 16 * c, cs, tev, evPer, used, drainBelow, &iters[(size_t)c]); };
+        auto job = [=, &rc, &iters]() { rc[(size_t)c] = run_cohort(device, sc, cam, cp, b, traceBlocks, h_cnt + 16 * c, cs, tev, evPer, used, drainBelow, &iters[(size_t)c], (unsigned long long*)traceStat); };
         if (C == 1) job(); else th.emplace_back(job);
     }
     for (auto& t : th) t.join();
@@ -699,6 +751,19 @@ hipError_t ptk_wf_render(int device, const ptd::DevScene* sc, const ptd::DevCame
     int mx = 0; for (int v : iters) mx = v > mx ? v : mx;
     if (iters_out) *iters_out = mx;
     return hipSuccess;
+}
+
+hipError_t ptk_dbg_pixel_dir(const ptd::DevCamera* cam, const int* pxpypass, int n, float* out8, hipStream_t stream)
+{
+    const int nb = (n + 255) / 256;
+    if (nb > 0) hipLaunchKernelGGL(ptd::dbg_pixel_dir, dim3(nb), dim3(256), 0, stream, *cam, pxpypass, n, out8);
+    return hipGetLastError();
+}
+hipError_t ptk_dbg_nee(const ptd::DevScene* sc, const float* in5, int n, float* out12, hipStream_t stream)
+{
+    const int nb = (n + ptd::kBlockThreads - 1) / ptd::kBlockThreads;
+    if (nb > 0) hipLaunchKernelGGL(ptd::dbg_nee, dim3(nb), dim3(ptd::kBlockThreads), 0, stream, *sc, in5, n, out12);
+    return hipGetLastError();
 }
 
 }  // extern "C"

@@ -1,5 +1,6 @@
 // ref_surface.cpp — see ref_surface.h.  Thin adaptors over the C-ABI.
 #include "ref_surface.h"
+#include <cstdio>
 
 #include <chrono>
 #include <cstdlib>
@@ -74,6 +75,16 @@ static void exportImage(Image& img, const float* raw, const char* path, int H, i
     std::cout << (img.WriteTo(path) ? "Export Success" : "Export failed") << std::endl;   // :114-121
 }
 
+static void write_raw(const std::string& path, const std::vector<float>& raw)
+{
+    if (path.empty()) return;
+    const std::string tmp = path + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    const bool ok = f && fwrite(raw.data(), 4, raw.size(), f) == raw.size();
+    if (f) fclose(f);
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) std::cout << "Export failed (" << path << ")" << std::endl;
+}
+
 void PathTracer::Render(Camera& camera, BVH* bvh)
 {
     using clk = std::chrono::system_clock;
@@ -112,6 +123,7 @@ void PathTracer::Render(Camera& camera, BVH* bvh)
             std::cout << "Sample " << i << " : Delta time : "
                       << std::chrono::duration_cast<std::chrono::milliseconds>(clk::now() - t0).count() << " (ms)" << std::endl;
             exportImage(img, raw.data(), "temp.png", H, W, i + 1);
+            write_raw(raw_path, raw);
         }
     } else {
         check(pt_render(scene, &cam, &params, raw.data()), "pt_render");
@@ -119,5 +131,6 @@ void PathTracer::Render(Camera& camera, BVH* bvh)
     }
     std::cout << "Delta time : " << std::chrono::duration_cast<std::chrono::milliseconds>(clk::now() - t0).count() << " (ms)" << std::endl;
     exportImage(img, raw.data(), "result.png", H, W, params.passes);
+    write_raw(raw_path, raw);
     pt_scene_destroy(scene);
 }

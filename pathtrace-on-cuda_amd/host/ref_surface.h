@@ -90,4 +90,8 @@ public:
     PathTracer() { pt_params_default(&params); }
     void Render(Camera& camera, BVH* bvh);  // writes temp.png / result.png in the CWD; GPU error -> message + exit(99)
     double last_render_ms = 0.0;            // kernel time of the last Render (sum over passes)
+    // Viewer hook (new; the reference's viewer only sees temp.png, srcs/renderer.cpp:283-293): when non-empty, the float accumulation
+    // buffer (W*H*3 float32, row-major, sum of per-pass means so far) is written to this path after every pass and at the end,
+    // atomically (temporary name + rename) — point it at /dev/shm and a viewer can map the frame while the render goes on.
+    std::string raw_path;
 };

@@ -85,6 +85,8 @@ API = [
     ("pt_dbg_bxdf", C.c_int, [C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     ("pt_dbg_rng", C.c_int, [C.c_int32, C.c_uint64, C.c_int32, _P, _P]),
     ("pt_dbg_math", C.c_int, [C.c_int32, _P, C.c_int32, _P]),
+    ("pt_dbg_pixel_dir", C.c_int, [C.c_int32, C.POINTER(PtCamera), _P, C.c_int32, _P]),
+    ("pt_dbg_nee", C.c_int, [_P, _P, C.c_int32, _P]),
     ("pt_dbg_triad", C.c_int, [C.c_int32, C.c_int64, C.c_int32, _P]),
     ("pt_dbg_valu_rate", C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("pt_last_counters", C.c_int, [_P, _P]),
@@ -258,7 +260,8 @@ class Scene:
         return out
 
     def render_tiles(self, cam, prm, d_tiles_ptr, d_work_ptr, stream_ptr=0):
-        """Asynchronous device-resident render of this rank's tiles (raw device pointers)."""
+        """Device-resident render of this rank's tiles (raw device pointers), enqueued on the given stream; blocks until the
+        render has drained in the default mode 1 (include/pt_api.h: pt_render_tiles)."""
         _check(lib().pt_render_tiles(self._h, C.byref(cam), C.byref(prm), C.c_void_p(d_tiles_ptr), C.c_void_p(d_work_ptr),
                                      C.c_void_p(stream_ptr)), "pt_render_tiles")
 
@@ -309,6 +312,13 @@ class Scene:
         out = raw.copy()
         out[:, 0] = np.where(raw[:, 0] != 0, ~raw[:, 0], 0)
         out[:, 1] = np.where(raw[:, 1] != 0, ~raw[:, 1], 0)
+        return out
+
+    def nee(self, in5):
+        """pt_dbg_nee: rows of (p.xyz, seed lo, seed hi as uint32 bits) -> (n, 12) float32 (see include/pt_api.h)."""
+        a = np.ascontiguousarray(in5, np.float32).reshape(-1, 5)
+        out = np.zeros((a.shape[0], 12), np.float32)
+        _check(lib().pt_dbg_nee(self._h, _ptr(a), a.shape[0], _ptr(out)), "pt_dbg_nee")
         return out
 
     def raycast(self, rays8):
@@ -410,6 +420,13 @@ def valu_rate(op=0, waves_per_simd=4, iters=20000, device=0):
     r, g = C.c_double(0.0), C.c_double(0.0)
     _check(lib().pt_dbg_valu_rate(int(device), int(op), int(waves_per_simd), int(iters), C.byref(r), C.byref(g)), "pt_dbg_valu_rate")
     return float(r.value), float(g.value)
+
+
+def dbg_pixel_dir(cam, pxpypass, device=0):
+    a = np.ascontiguousarray(pxpypass, np.int32).reshape(-1, 3)
+    out = np.zeros((a.shape[0], 8), np.float32)
+    _check(lib().pt_dbg_pixel_dir(device, C.byref(cam), _ptr(a), a.shape[0], _ptr(out)), "pt_dbg_pixel_dir")
+    return out
 
 
 def dbg_math(x, device=0):

@@ -62,7 +62,8 @@ class TileRenderer:
         self.work = torch.empty(work_bytes(cam, prm) // 4, dtype=torch.float32, device=device)
 
     def render(self):
-        """Asynchronous on torch's current stream."""
+        """Enqueued on torch's current stream.  Blocks the calling thread until the render has drained in the default
+        render path (pt_render_tiles polls the live-stream count, include/pt_api.h); asynchronous only in mode 0."""
         stream = self.torch.cuda.current_stream(self.device).cuda_stream
         self.scene.render_tiles(self.cam, self.prm, self.tiles.data_ptr(), self.work.data_ptr(), stream)
         return self.tiles

@@ -64,6 +64,8 @@ def lib():
         l.o_render.argtypes = [P, C.POINTER(OCamera), C.POINTER(OParams), P, P, C.c_int]
         l.o_tonemap.argtypes = [P, C.c_int, C.c_int, P]
         l.o_u8.argtypes = [P, C.c_int, P]
+        l.o_pixel_dir.argtypes = [C.POINTER(OCamera), P, C.c_int, P]
+        l.o_nee.argtypes = [P, P, C.c_int, P]
         l.o_bxdf.argtypes = [C.c_int, P, C.c_int, P]
         _lib = l
     return _lib
@@ -176,6 +178,12 @@ class Scene:
         lib().o_raycast(self._h, _p(rays8), n, _p(hits), _p(prim), _p(cnt))
         return hits, prim, cnt
 
+    def nee(self, in5):
+        a = np.ascontiguousarray(in5, np.float32).reshape(-1, 5)
+        out = np.zeros((a.shape[0], 12), np.float32)
+        lib().o_nee(self._h, _p(a), a.shape[0], _p(out))
+        return out
+
     def render(self, cam, prm, nthreads=8, accum=None):
         if accum is None:
             accum = np.zeros((cam.H, cam.W, 3), np.float32)
@@ -190,6 +198,13 @@ def tonemap(raw, sample_cnt):
     raw = np.ascontiguousarray(raw, np.float32)
     out = np.zeros(raw.shape, np.uint8)
     lib().o_tonemap(_p(raw), raw.size // 3, sample_cnt, _p(out))
+    return out
+
+
+def pixel_dir(cam, pxpypass):
+    a = np.ascontiguousarray(pxpypass, np.int32).reshape(-1, 3)
+    out = np.zeros((a.shape[0], 8), np.float32)
+    lib().o_pixel_dir(C.byref(cam), _p(a), a.shape[0], _p(out))
     return out
 
 

@@ -191,6 +191,41 @@ def test_tile_split_is_bitwise_invariant():
         assert np.array_equal(bits(gathered.cpu().numpy().reshape(-1, 3)[idx].reshape(H, W, 3)), bits(base))
 
 
+def test_pixel_direction_table():
+    """StartRender's prologue + GetPixelDirection (srcs/pathtracer.cu:33-40,70-74), row by row: jitter draws, direction bits and
+    the RNG position afterwards, for corner / edge / random pixels of three frame shapes and several passes."""
+    rs = np.random.RandomState(5)
+    for W, H in ((1920, 1080), (3840, 2160), (100, 52)):
+        px = np.concatenate([[0, W - 1, 0, W - 1, W // 2], rs.randint(0, W, 3000)])
+        py = np.concatenate([[0, 0, H - 1, H - 1, H // 2], rs.randint(0, H, 3000)])
+        ps = np.concatenate([[0, 1, 7, 7, 3], rs.randint(0, 8, 3000)])
+        rows = np.stack([px, py, ps], 1).astype(np.int32)
+        got = ptamd.dbg_pixel_dir(ptamd.make_camera(W, H), rows)
+        want = O.pixel_dir(O.make_camera(W, H), rows)
+        assert np.array_equal(bits(got), bits(want)), (W, H)
+        assert np.all(np.abs(np.linalg.norm(got[:, 2:5], axis=1) - 1) < 1e-6)
+
+
+def test_nee_table():
+    """One NEE sample per row (SamplePrimitive, pdf, cosA: include/CudaUtil.cuh:38-48,235-241) and its visibility (GetLightColor,
+    :150-166: shadow ray's closest hit, EPS test, emittance), on the stand-in scene with the test spheres, from surface points
+    found by casting rays into the scene plus points on and above the light."""
+    prims = ptamd.gen_scene(1, 24)
+    nodes, tris, _ = ptamd.build_bvh(prims)
+    sph = make_test_spheres()
+    sg, so = ptamd.Scene(nodes, tris, sph), O.Scene(nodes.tobytes(), tris, sph)
+    rs = np.random.RandomState(11)
+    hits, prim, _ = so.raycast(scene_rays8(6000, rs))
+    pts = hits[prim >= 0][:, 5:8]                                  # HitResult.p of rays that hit something
+    pts = np.concatenate([pts, np.stack([rs.uniform(-5, 5, 200), np.full(200, 39.98), rs.uniform(-5, 5, 200)], 1),
+                          np.stack([rs.uniform(-20, 20, 200), np.full(200, 39.999), rs.uniform(-20, 20, 200)], 1)]).astype(np.float32)
+    seeds = rs.randint(0, 2**32, (pts.shape[0], 2), dtype=np.uint64).astype(np.uint32)
+    in5 = np.concatenate([pts, seeds.view(np.float32)], 1)
+    got, want = sg.nee(in5), so.nee(in5)
+    assert (want[:, 8:11].sum(1) > 0).sum() > 1000 and (want[:, 8:11].sum(1) == 0).sum() > 1000      # lit and shadowed rows both present
+    assert np.array_equal(bits(got), bits(want))
+
+
 def test_c_abi_gather_frame_world1():
     """The C-ABI's exchange step (pt_comm_create / pt_gather_frame) with a world of one: a device copy + pt_untile, bit for bit
     the frame pt_render returns.  (world > 1 runs ncclGather and needs one GPU per rank: unmeasured on this one-GPU box.)"""

@@ -132,7 +132,8 @@ def test_cli_render_matches_library_and_oracle(tmp_path):
     W, H, passes, spp = 96, 56, 3, 4
     r = subprocess.run([PTRENDER, "--scene", "standin", "--lat-lon", "16", "--glass-sphere", "--obj", str(tmp_path / "cube.obj"),
                         "--obj-scale", "6", "--obj-translate", "-14,0,4", "--width", str(W), "--height", str(H),
-                        "--passes", str(passes), "--spp", str(spp), "--depth", "12"], cwd=tmp_path, capture_output=True, text=True)
+                        "--passes", str(passes), "--spp", str(spp), "--depth", "12", "--raw", str(tmp_path / "accum.f32")],
+                       cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout.count("Export Success") == passes + 1 and "Maximum depth of tree" in r.stdout and "ADD light" in r.stdout
     prims = np.concatenate([ptamd.gen_scene(1, 16), load_obj(str(tmp_path / "cube.obj"), 6.0, (-14, 0, 4))])
@@ -141,6 +142,8 @@ def test_cli_render_matches_library_and_oracle(tmp_path):
     img = ptamd.Scene(nodes, tris, glass).render(ptamd.make_camera(W, H), ptamd.default_params(passes=passes, spp_per_pass=spp, max_bounce=12))
     assert np.array_equal(_read_png(str(tmp_path / "result.png")), ptamd.tonemap_u8(img, passes))
     assert os.path.exists(tmp_path / "temp.png")
+    raw = np.fromfile(str(tmp_path / "accum.f32"), np.float32).reshape(H, W, 3)       # --raw: the float accumulation buffer (viewer hook)
+    assert np.array_equal(raw.view(np.uint32), img.view(np.uint32))
     O.set_libm(1)
     ref, _ = O.Scene(nodes.tobytes(), tris, glass).render(O.make_camera(W, H), O.make_params(W, H, passes, spp, max_bounce=12), 8)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
