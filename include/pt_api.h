@@ -199,6 +199,9 @@ PT_API int32_t pt_comm_world(const PtComm* c);
 PT_API int  pt_gather_tiles(PtComm* c, const float* d_tiles, int64_t n_floats, float* d_gathered, void* hip_stream);
 PT_API int  pt_gather_frame(PtComm* c, const float* d_tiles, const PtCamera* cam, const PtParams* prm,
                             float* d_gathered, float* d_frame_rgb, void* hip_stream);
+/* The multi-GPU sibling of pt_render for hosts without HIP code of their own: this rank's tiles, the gather, and on rank 0 the
+ * assembled frame in h_accum_rgb[W*H*3] (ignored elsewhere).  Rank and world come from the communicator.  Synchronous. */
+PT_API int  pt_render_split(PtScene* s, const PtCamera* cam, const PtParams* prm, PtComm* c, float* h_accum_rgb);
 
 /* ----------------------------------------------------------------------------------
  * (a12,a13) Output + camera helpers (host).

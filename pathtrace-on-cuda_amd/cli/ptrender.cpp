@@ -15,6 +15,7 @@ static void usage()
         "usage: ptrender [--scene cornell|standin|standin4] [--obj FILE --obj-scale S --obj-translate X,Y,Z]\n"
         "                [--glass-sphere] [--width W] [--height H] [--passes N] [--spp N] [--depth N]\n"
         "                [--lat-lon N] [--device D] [--no-progressive] [--raw FILE]\n"
+        "                [--world N --rank R --id-file PATH]   (one process per GPU; rank 0 writes the frame)\n"
         "Writes temp.png (per pass) and result.png in the current directory, like PathTracer::Render.\n"
         "--raw FILE: also writes the float accumulation buffer (W*H*3 float32) there after every pass (viewer hook).\n"
         "Defaults: scene cornell, 1920x1080, 8 passes x 64 spp, depth 8.\n";
@@ -26,6 +27,7 @@ int main(int argc, char** argv)
     float objScale = 1.f; float objT[3] = {0, 0, 0};
     int W = 1920, H = 1080, passes = 8, spp = 64, depth = 8, latlon = 187, device = 0;
     bool glass = false, progressive = true;
+    int rank = 0, world = 1; std::string idFile;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> const char* { if (i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };
@@ -43,9 +45,13 @@ int main(int argc, char** argv)
         else if (a == "--device") device = atoi(next());
         else if (a == "--no-progressive") progressive = false;
         else if (a == "--raw") rawPath = next();
+        else if (a == "--world") world = atoi(next());
+        else if (a == "--rank") rank = atoi(next());
+        else if (a == "--id-file") idFile = next();
         else if (a == "--help" || a == "-h") { usage(); return 0; }
         else { std::cerr << "unknown option " << a << "\n"; usage(); return 2; }
     }
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && idFile.empty())) { std::cerr << "--world N needs 0 <= --rank < N and --id-file PATH\n"; return 2; }
     const int kind = scene == "cornell" ? 0 : scene == "standin" ? 1 : scene == "standin4" ? 2 : -1;
     if (kind < 0) { std::cerr << "unknown scene " << scene << "\n"; return 2; }
 
@@ -71,6 +77,7 @@ int main(int argc, char** argv)
     PathTracer tracer;
     tracer.params.passes = passes; tracer.params.spp_per_pass = spp; tracer.params.max_bounce = depth;
     tracer.device = device; tracer.progressive = progressive; tracer.raw_path = rawPath;
+    tracer.rank = rank; tracer.world = world; tracer.id_file = idFile;
     tracer.Render(camera, &bvh);
     const double samples = (double)W * H * passes * spp;
     std::cout << "{\"msamples_per_s_kernel\": " << samples / (tracer.last_render_ms * 1e-3) / 1e6 << ", \"kernel_ms\": " << tracer.last_render_ms << "}" << std::endl;

@@ -181,4 +181,34 @@ int pt_gather_frame(PtComm* c, const float* d_tiles, const PtCamera* cam, const 
     return PT_OK;
 }
 
+// Whole-frame convenience for a host program without HIP code of its own (the multi-GPU sibling of pt_render): renders this
+// rank's tiles for all passes, runs the single gather, and on rank 0 copies the assembled frame to h_accum_rgb[W*H*3]
+// (ignored on the other ranks).  prm->rank / prm->world are taken from the communicator.  Synchronous.
+int pt_render_split(PtScene* s, const PtCamera* cam, const PtParams* prm, PtComm* c, float* h_accum_rgb)
+{
+    if (!s || !cam || !prm || !c || (c->rank == 0 && !h_accum_rgb)) { pt_set_error("pt_render_split: NULL argument"); return PT_ERR_INVALID; }
+    PtParams p = *prm; p.rank = c->rank; p.world = c->world;
+    const int64_t nt = pt_tiles_floats(cam, &p), wb = pt_work_bytes(cam, &p);
+    if (nt < 0 || wb < 0) return PT_ERR_INVALID;
+    HIPCHK(hipSetDevice(c->device));
+    float *d_tiles = nullptr, *d_gathered = nullptr, *d_frame = nullptr; void* d_work = nullptr;
+    auto body = [&]() -> int {
+        HIPCHK(hipMalloc((void**)&d_tiles, (size_t)nt * 4));
+        HIPCHK(hipMalloc(&d_work, (size_t)wb));
+        if (c->rank == 0) {
+            HIPCHK(hipMalloc((void**)&d_gathered, (size_t)nt * 4 * (size_t)c->world));
+            HIPCHK(hipMalloc((void**)&d_frame, (size_t)cam->W * cam->H * 12));
+        }
+        int r = pt_render_tiles(s, cam, &p, d_tiles, d_work, nullptr);
+        if (!r) r = pt_gather_frame(c, d_tiles, cam, &p, d_gathered, d_frame, nullptr);
+        if (r) return r;
+        HIPCHK(hipDeviceSynchronize());
+        if (c->rank == 0) HIPCHK(hipMemcpy(h_accum_rgb, d_frame, (size_t)cam->W * cam->H * 12, hipMemcpyDeviceToHost));
+        return PT_OK;
+    };
+    const int rc = body();
+    (void)hipFree(d_tiles); (void)hipFree(d_work); (void)hipFree(d_gathered); (void)hipFree(d_frame);
+    return rc;
+}
+
 }  // extern "C"

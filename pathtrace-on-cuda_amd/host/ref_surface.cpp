@@ -112,7 +112,15 @@ void PathTracer::Render(Camera& camera, BVH* bvh)
     std::vector<float> raw((size_t)W * H * 3, 0.f), pass((size_t)W * H * 3);
     const auto t0 = clk::now();
     last_render_ms = 0.0;
-    if (progressive) {
+    if (world > 1) {
+        // one process per GPU: this rank's tiles for all passes, one gather (RCCL), frame on rank 0
+        PtComm* comm = nullptr;
+        check(pt_comm_create_from_file(id_file.c_str(), rank, world, device, 120, &comm), "pt_comm_create_from_file");
+        check(pt_render_split(scene, &cam, &params, comm, raw.data()), "pt_render_split");
+        float ms = 0.f; pt_last_render_ms(scene, &ms); last_render_ms = ms;
+        pt_comm_destroy(comm);
+        if (rank != 0) { pt_scene_destroy(scene); return; }
+    } else if (progressive) {
         // one call per pass, summed in pass order: bit-identical to a single multi-pass call, and temp.png
         // can be rewritten after every pass as the reference does (srcs/pathtracer.cu:236-246)
         for (int i = 0; i < params.passes; i++) {

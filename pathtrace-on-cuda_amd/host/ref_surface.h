@@ -94,4 +94,8 @@ public:
     // buffer (W*H*3 float32, row-major, sum of per-pass means so far) is written to this path after every pass and at the end,
     // atomically (temporary name + rename) — point it at /dev/shm and a viewer can map the frame while the render goes on.
     std::string raw_path;
+    // Tile split over several processes, one per GPU (new; the reference is single-device): this process renders tiles
+    // t % world == rank; the ranks meet through `id_file` (pt_comm_create_from_file) and rank 0 assembles and exports the frame.
+    int rank = 0, world = 1;
+    std::string id_file;
 };

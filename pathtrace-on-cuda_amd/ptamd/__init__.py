@@ -75,6 +75,7 @@ API = [
     ("pt_comm_world", C.c_int32, [_P]),
     ("pt_gather_tiles", C.c_int, [_P, _P, C.c_int64, _P, _P]),
     ("pt_gather_frame", C.c_int, [_P, _P, C.POINTER(PtCamera), C.POINTER(PtParams), _P, _P, _P]),
+    ("pt_render_split", C.c_int, [_P, C.POINTER(PtCamera), C.POINTER(PtParams), _P, _P]),
     ("pt_tonemap_u8", C.c_int, [_P, C.c_int64, C.c_int32, _P]),
     ("pt_convert_u8", C.c_int, [_P, C.c_int64, _P]),
     ("pt_write_png", C.c_int, [C.c_char_p, _P, C.c_int32, C.c_int32, C.c_int32]),
@@ -379,6 +380,12 @@ class Comm:
     def gather_frame(self, d_tiles_ptr, cam, prm, d_gathered_ptr, d_frame_ptr, stream_ptr=0):
         _check(lib().pt_gather_frame(self._h, C.c_void_p(d_tiles_ptr), C.byref(cam), C.byref(prm), C.c_void_p(d_gathered_ptr),
                                      C.c_void_p(d_frame_ptr), C.c_void_p(stream_ptr)), "pt_gather_frame")
+
+    def render_split(self, scene, cam, prm):
+        """pt_render_split: this rank's share + the gather; returns the (H, W, 3) frame on rank 0, None elsewhere."""
+        out = np.zeros((cam.H, cam.W, 3), np.float32) if self.rank == 0 else None
+        _check(lib().pt_render_split(scene.handle, C.byref(cam), C.byref(prm), self._h, _ptr(out) if out is not None else None), "pt_render_split")
+        return out
 
     def close(self):
         if self._h:

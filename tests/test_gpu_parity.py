@@ -191,6 +191,23 @@ def test_tile_split_is_bitwise_invariant():
         assert np.array_equal(bits(gathered.cpu().numpy().reshape(-1, 3)[idx].reshape(H, W, 3)), bits(base))
 
 
+def test_scaled_scene_shadow_early_out():
+    """Cornell room + small stand-in scaled x100 (coordinates in the thousands, where ulp(coordinate) exceeds the reference's EPS = 1e-4):
+    the shadow rays' any-hit early-out keeps its margin above the rounding of org + t*dir (pt_stream.h: shadow_stop_t), so the image
+    still equals the oracle's — which always takes the closest hit — bit for bit."""
+    prims = ptamd.gen_scene(1, 12).copy()
+    for v in range(3):
+        prims[:, 28 * v:28 * v + 3] *= 100.0                      # Vertex.Position of the three vertices
+    nodes, tris, _ = ptamd.build_bvh(prims)
+    W, H = 96, 64
+    pos = (0.0, 2000.0, 6000.0)
+    img = ptamd.Scene(nodes, tris).render(ptamd.make_camera(W, H, pos=pos), ptamd.default_params(passes=2, spp_per_pass=8))
+    O.set_libm(1)
+    ref, _ = O.Scene(nodes.tobytes(), tris).render(O.make_camera(W, H, pos=pos), O.make_params(W, H, 2, 8), 8)
+    _check_image(img, ref, "scaled x100")
+    assert np.array_equal(bits(img), bits(ref))
+
+
 def test_pixel_direction_table():
     """StartRender's prologue + GetPixelDirection (srcs/pathtracer.cu:33-40,70-74), row by row: jitter draws, direction bits and
     the RNG position afterwards, for corner / edge / random pixels of three frame shapes and several passes."""
@@ -246,6 +263,7 @@ def test_c_abi_gather_frame_world1():
     comm.gather_frame(tiles.data_ptr(), cam, prm, gathered.data_ptr(), frame.data_ptr(), stream)
     torch.cuda.synchronize()
     assert np.array_equal(bits(frame.cpu().numpy()), bits(base))
+    assert np.array_equal(bits(comm.render_split(sc, cam, prm)), bits(base))        # pt_render_split: the whole thing in one call
     with pytest.raises(ptamd.PtError):          # params of another split than the communicator's
         comm.gather_frame(tiles.data_ptr(), cam, ptamd.default_params(passes=2, spp_per_pass=4, rank=0, world=2), gathered.data_ptr(), frame.data_ptr(), stream)
     comm.close()
