@@ -87,7 +87,9 @@ PT_DEV f3 sample_microfacet(float roughness, const Frame& h, Rng& s) {          
     float phi = (2.f * kPi) * s.uniform();
     float ry = s.uniform();
     float theta = cr_atan(roughness * __builtin_sqrtf(ry / (1.f - ry)));
-    float cp = cr_cos(phi), sp = cr_sin(phi), ct = cr_cos(theta), st = cr_sin(theta);
+    float cp, sp, ct, st;
+    cr_sincos(phi, sp, cp);
+    cr_sincos(theta, st, ct);
     float lx = cp * st, ly = sp * st, lz = ct;
     return lx * h.t + ly * h.b + lz * h.n;
 }
@@ -101,8 +103,8 @@ PT_DEV f3 sample_hemisphere(Rng& s, const Frame& h) {                           
     float phi = (2.f * kPi) * s.uniform();
     float cosTheta = __builtin_sqrtf(s.uniform());
     float sinTheta = __builtin_sqrtf(1.f - cosTheta * cosTheta);
-    float cosPhi = cr_cos(phi);
-    float sinPhi = cr_sin(phi);
+    float cosPhi, sinPhi;
+    cr_sincos(phi, sinPhi, cosPhi);
     float x = cosPhi * sinTheta, y = sinPhi * sinTheta, z = cosTheta;
     return normalize(x * h.t + y * h.b + z * h.n);
 }
