@@ -653,10 +653,11 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     static const int guideShift = getenv("PTAMD_GS") ? atoi(getenv("PTAMD_GS")) : 9;
     static const int budgetShift = getenv("PTAMD_BS") ? atoi(getenv("PTAMD_BS")) : 14;
     static const int budgetMin = getenv("PTAMD_BM") ? atoi(getenv("PTAMD_BM")) : kWfBudget;
-    static const int shadeWaves = getenv("PTAMD_SW") ? atoi(getenv("PTAMD_SW")) : 3;
-    // workgroup size of wf_shade: 256 threads = one wave per SIMD, so three (SW=3) workgroups share a CU and retire
-    // independently (measured: 64 -28 %, 128 -4 %, 192 -1 %, 384 -22 %, 512 -12 %, 768 -5 %)
-    static const int shadeThreads = (getenv("PTAMD_ST") && atoi(getenv("PTAMD_ST")) >= 64 && atoi(getenv("PTAMD_ST")) <= 512) ? (atoi(getenv("PTAMD_ST")) & ~63) : 256;
+    static const int shadeWaves = getenv("PTAMD_SW") ? atoi(getenv("PTAMD_SW")) : 4;
+    // wf_shade: 4 waves/SIMD (128 VGPRs, 12 of them spilled) in 512-thread workgroups = two per CU (round 2, after sin/cos pairs went through
+    // one sincos: 1462 vs 1418 Msamples/s for 3 waves/SIMD without spills in 256-thread workgroups; other shapes at 4 waves: 384 threads
+    // -13 %, 448 -8 %; at 3 waves: 128 -5 %, 192 -3 %, 384 -23 %)
+    static const int shadeThreads = (getenv("PTAMD_ST") && atoi(getenv("PTAMD_ST")) >= 64 && atoi(getenv("PTAMD_ST")) <= kShadeThreads) ? (atoi(getenv("PTAMD_ST")) & ~63) : 512;
     static const int refillMin = getenv("PTAMD_RF") ? atoi(getenv("PTAMD_RF")) : kWfRefill;     // idle lanes that trigger a refill
     static const int triTrig = getenv("PTAMD_TT") ? atoi(getenv("PTAMD_TT")) : 64;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
