@@ -263,7 +263,8 @@ PT_API int  pt_last_counters(PtScene* s, int64_t* out8);
 /* Diagnostic (environment PTAMD_TSTAT=1 only): per wf_trace launch of the last render, in 100 MHz ticks:
  * ~(earliest wave start), ~(earliest time a wave found the ray queue empty; 0 = never), latest wave exit.
  * With PTAMD_TSTAT=1 pt_last_counters returns wf_trace's trip counters instead of the work counters.
- * n_launches = 0: out3n receives 32 int64 instead — the histogram of wave lifetimes in 32-microsecond bins. */
+ * n_launches = 0: out3n receives 32 int64 instead — the histogram of wave lifetimes in 32-microsecond bins.
+ * n_launches = -n: out3n receives n int64 — the number of rays each of the first n launches traced. */
 PT_API int  pt_dbg_trace_timeline(PtScene* s, int64_t* out3n, int32_t n_launches);
 /* Render path: 1 = queue-driven wavefront pipeline (default: traversal and shading are
  * separate kernels, lanes refill from a ray queue), 0 = the one-kernel state machine.

@@ -155,7 +155,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
     const uint32_t nPath = b.cnt[slot].nRays[0][0];
     const uint32_t nKind1 = nPath + b.cnt[slot].nRays[1][0];
     const uint32_t n = nKind1 + b.cnt[slot].nRays[2][0];
-    if ((uint32_t)blockIdx.x * 256u >= n) return;      // surplus blocks leave before touching the queue
+    if ((uint32_t)blockIdx.x * 256u >= n) return;      // surplus blocks leave before touching the queue (fewer rays per workgroup: no faster, r02_b21.log)
 #if TRACE_TOP_NODES > 0
     __shared__ uint4 lds_top[kTopNodes * kTopStride];
     const int topN = min(min(topWant, kTopNodes), sc.n_quad);
@@ -436,6 +436,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
             unsigned long long* hist = stat + 8 + 3 * 2700;
             const unsigned long long dtk = (tEnd - stT0) / 3200ull;      // 32 us bins (100 MHz ticks)
             atomicAdd(&hist[dtk < 31 ? dtk : 31], 1ull);
+            if (blockIdx.x == 0 && threadIdx.x == 0) hist[32 + statLaunch] = n;      // rays of this launch
             if (STAT) { atomicAdd(&stat[4], stRefills); atomicAdd(&stat[5], stRefillLanes); atomicAdd(&stat[6], stNoRayLanes); atomicAdd(&stat[7], r); }
         }
     }

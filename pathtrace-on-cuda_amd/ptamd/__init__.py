@@ -322,6 +322,12 @@ class Scene:
         _check(lib().pt_dbg_nee(self._h, _ptr(a), a.shape[0], _ptr(out)), "pt_dbg_nee")
         return out
 
+    def trace_launch_rays(self, n_launches):
+        """Diagnostic (PTAMD_TSTAT=1 or 2): rays traced by each of the first n wf_trace launches of the last render."""
+        raw = np.zeros(int(n_launches), np.int64)
+        _check(lib().pt_dbg_trace_timeline(self._h, _ptr(raw), -int(n_launches)), "pt_dbg_trace_timeline")
+        return raw
+
     def raycast(self, rays8):
         rays8 = np.ascontiguousarray(rays8, np.float32).reshape(-1, 8)
         n = rays8.shape[0]
