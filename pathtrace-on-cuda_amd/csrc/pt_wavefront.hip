@@ -220,7 +220,8 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     uint32_t start = 0;
                     if (lane == 0) start = atomicAdd(&b.cnt[slot].head[shard].v, want);
                     start = __builtin_amdgcn_readfirstlane(start);
-                    if (start < cnt) { chunkPos = start; chunkEnd = (cnt - start > want) ? start + want : cnt; seenLeft = cnt - start; break; }
+                    if (start < cnt) {
+                        chunkPos = start; chunkEnd = (cnt - start > want) ? start + want : cnt; seenLeft = cnt - start; break; }
                     seenLeft = 0xffffffffu;
                     shard = (shard + 1) % kWfShards;
                     if (++shardsTried >= kWfShards) { exhausted = true; if (timeline) stTExh = __builtin_amdgcn_s_memrealtime(); break; }
