@@ -419,7 +419,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 }
                 (kind == 0 ? b.hit[0] : (kind == 1 ? b.hit[1] : b.hit[2]))[sid] = make_float2(bestT, __int_as_float(bestPrim));
                 hasRay = false;
-                if (STAT) stRays++;
+                if (STAT) { stRays++; atomicAdd(&stat[8 + 3 * 2700 + 32 + 2700 + (steps >= 252 ? 63 : steps >> 2)], 1ull); }      // node steps of this ray (this launch), bins of 4
             }
         }
     }

@@ -33,3 +33,7 @@ h = np.zeros(32, np.int64)
 ptamd.lib().pt_dbg_trace_timeline(sc._h, h.ctypes.data_as(C.c_void_p), 0)
 tot = max(1, int(h.sum()))
 print("wave lifetimes, 32-us bins (all launches pooled), % of waves:", " ".join("%.1f" % (100.0 * x / tot) for x in h[:24]))
+hs = np.zeros(64, np.int64)
+ptamd.lib().pt_dbg_trace_timeline(sc._h, hs.ctypes.data_as(C.c_void_p), -3000)
+tot = max(1, int(hs.sum())); cum = np.cumsum(hs[::-1])[::-1] / tot
+print("node steps per ray, fraction of rays with >= N steps:", " ".join("%d:%.2e" % (4 * k, cum[k]) for k in (0, 2, 4, 6, 8, 12, 16, 24, 32, 40, 48, 63)))
