@@ -19,3 +19,23 @@ tail -1 gpurun_out/r02_emulate_world.log > gpurun_out/r02_emulated_world.json
 python3 -c "
 import json; d=json.load(open('gpurun_out/r02_emulated_world.json'))
 for w,v in d['worlds'].items(): print('world',w,'slowest %.4f s'%v['slowest_s'],'implied speed-up %.2f'%v.get('implied_speedup_vs_1',1.0))"
+# rocprofv3 kernel trace + stats of the default bench command (no counters in this run)
+export TMPDIR=/tmp
+rm -rf /tmp/prof_final && (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_final -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-probes > $GRAFT_REPO_ROOT/gpurun_out/r02_prof_bench.log 2>&1)
+find /tmp/prof_final -name "*kernel_stats.csv" -exec cp {} gpurun_out/r02_rocprofv3_kernel_stats.csv \;
+KT=$(find /tmp/prof_final -name "*kernel_trace.csv" | head -1)
+python3 - "$KT" <<'PY'
+import csv, json, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1]))]
+out = {}
+inits = sorted(int(r["Start_Timestamp"]) for r in rows if "wf_init" in r["Kernel_Name"])
+for key in ("wf_trace", "wf_shade"):
+    d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows if key in r["Kernel_Name"])
+    timed = [x[1] for x in d if x[0] > inits[-1]]      # launches after the wf_init of the second (timed) render
+    out[key] = {"launches_total": len(d), "launches_timed_render": len(timed), "avg_ns_timed_render": sum(timed) / max(1, len(timed)),
+                "sum_ms_timed_render": sum(timed) / 1e6, "avg_ns_all": sum(x[1] for x in d) / max(1, len(d))}
+out["command"] = "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-probes"
+out["note"] = "bench.py renders a 1-pass warm-up before the timed 8-pass call; its roofline.kernel_ms_avg (HIP events) covers the timed call only"
+json.dump(out, open("gpurun_out/r02_rocprofv3_timed_render_breakdown.json", "w"), indent=1)
+print(json.dumps(out["wf_trace"]))
+PY
