@@ -388,6 +388,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     sp--;
                     cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride];
                 }
+                if (STAT) atomicAdd(&stat[8 + 3 * 2700 + 32 + 2700 + 64 + (sp > 31 ? 31 : sp)], 1ull);      // stack depth after this node step
                 if (cur < 0 && cur != kDone && pend == 0) {
                     // park the leaf, carry on with the next stack entry
                     pend = cur;

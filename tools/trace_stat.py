@@ -37,3 +37,7 @@ hs = np.zeros(64, np.int64)
 ptamd.lib().pt_dbg_trace_timeline(sc._h, hs.ctypes.data_as(C.c_void_p), -3000)
 tot = max(1, int(hs.sum())); cum = np.cumsum(hs[::-1])[::-1] / tot
 print("node steps per ray, fraction of rays with >= N steps:", " ".join("%d:%.2e" % (4 * k, cum[k]) for k in (0, 2, 4, 6, 8, 12, 16, 24, 32, 40, 48, 63)))
+hd = np.zeros(32, np.int64)
+ptamd.lib().pt_dbg_trace_timeline(sc._h, hd.ctypes.data_as(C.c_void_p), -3001)
+tot = max(1, int(hd.sum())); cum = np.cumsum(hd[::-1])[::-1] / tot
+print("stack depth after a node step: mean %.2f; fraction of node steps with depth >= N:" % (float((hd * np.arange(32)).sum()) / tot), " ".join("%d:%.2e" % (k, cum[k]) for k in (1, 2, 4, 6, 8, 10, 12, 14, 16, 20)))
