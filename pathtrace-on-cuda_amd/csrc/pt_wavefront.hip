@@ -459,7 +459,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
 // ---------------------------------------------------------------------------------------
 constexpr int kFree = (int)0x80000001;      // slot state: holds no ray
 __global__ __launch_bounds__(256, 4)
-void wg_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift)
+void wg_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift, int refillMin)
 {
     __shared__ float4 sA[256];              // org.xyz | closest t
     __shared__ float4 sB[256];              // inv.xyz | cscale
@@ -649,7 +649,7 @@ void wg_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     sC[s] = make_int4(cur, sp, pend, bestPrim);
                 }
             }
-        } else if (wave == Wn + Wt && !exhausted && tot[2] > 0u) {
+        } else if (wave == Wn + Wt && !exhausted && (tot[2] >= (uint32_t)refillMin || tot[0] + tot[1] < 64u)) {
             // ================= refill: one wave hands new rays to free slots =================
             uint32_t chunkPos = sQ[0], chunkEnd = sQ[1], seenLeft = sQ[5];
             int shard = (int)sQ[2], shardsTried = (int)sQ[3];
@@ -944,6 +944,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     static const int triTrig = getenv("PTAMD_TT") ? atoi(getenv("PTAMD_TT")) : 64;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
     static const bool wgTrace = getenv("PTAMD_WG") && atoi(getenv("PTAMD_WG")) != 0;        // experiment: wg_trace instead of wf_trace
+    static const int wgRefill = (getenv("PTAMD_WGR") && atoi(getenv("PTAMD_WGR")) >= 1) ? atoi(getenv("PTAMD_WGR")) : 48;
     static const int wgBlocks = (getenv("PTAMD_WGB") && atoi(getenv("PTAMD_WGB")) >= 1) ? atoi(getenv("PTAMD_WGB")) : 1024;
     static const int topNodes = getenv("PTAMD_TOP") ? atoi(getenv("PTAMD_TOP")) : kTopNodes;      // quad nodes staged in LDS (0 = none)
     static const bool traceStatFull = getenv("PTAMD_TSTAT") && atoi(getenv("PTAMD_TSTAT")) == 1;      // 1: trip counters too (slower build); 2: timeline only
@@ -957,7 +958,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
             const bool timed = trace_ev && it < trace_ev_pairs;
             if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
-            if (wgTrace && !traceStat) hipLaunchKernelGGL(wg_trace, dim3(nb < wgBlocks ? nb : wgBlocks), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift);
+            if (wgTrace && !traceStat) hipLaunchKernelGGL(wg_trace, dim3(nb < wgBlocks ? nb : wgBlocks), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, wgRefill);
             else if (traceStat && traceStatFull) hipLaunchKernelGGL(wf_trace<1>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
             else if (traceStat) hipLaunchKernelGGL(wf_trace<2>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
             else hipLaunchKernelGGL(wf_trace<0>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, 0);
