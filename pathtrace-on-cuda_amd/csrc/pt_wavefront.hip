@@ -445,285 +445,6 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
 }
 
 // ---------------------------------------------------------------------------------------
-// wg_trace: the same traversal with the rays of a workgroup pooled in LDS (experiment, PTAMD_WG=1).
-//
-// wf_trace keeps a ray in the registers of one lane from refill to completion, so every trip serves only the lanes whose ray
-// happens to need that kind of trip (69 % of them) and a wave lives as long as its longest ray.  Here a workgroup owns 256 ray
-// SLOTS in LDS (origin, inverse direction, closest hit, stack: 144 B each) and works in rounds: every thread reports what its own
-// slot needs next (a node step, a triangle test, a new ray), the slots are compacted into three lists, and whole waves are then
-// given one kind of work each — wave w processes list entries 64w .. 64w+63, whichever slots those are.  Trips are dense whatever
-// the mix, a long ray occupies a slot and not a lane, and the per-ray state no longer competes for registers.
-// The price: two barriers and ~60 instructions of list building per round, the state crosses LDS once per trip, and 4 workgroups
-// per CU (LDS) = 4 waves per SIMD.
-// Same arithmetic as wf_trace (node step, tri_test_pair, tie rule, suspension records), so results are bit-identical.
-// ---------------------------------------------------------------------------------------
-constexpr int kFree = (int)0x80000001;      // slot state: holds no ray
-__global__ __launch_bounds__(256, 4)
-void wg_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift, int refillMin)
-{
-    __shared__ float4 sA[256];              // org.xyz | closest t
-    __shared__ float4 sB[256];              // inv.xyz | cscale
-    __shared__ float4 sE[256];              // dir.xyz | stopBelow
-    __shared__ int4 sC[256];                // cur | sp | pend | closest prim
-    __shared__ int2 sD[256];                // stream id | kind + (degenerate << 2) + (steps << 3)
-    __shared__ int sStack[kWfLdsStack][256];
-    __shared__ unsigned char sList[3][256];
-    __shared__ uint32_t sCnt[3][4];
-    __shared__ uint32_t sQ[8];              // chunkPos, chunkEnd, shard, shardsTried, exhausted, seenLeft
-    const uint32_t nPath = b.cnt[slot].nRays[0][0];
-    const uint32_t nKind1 = nPath + b.cnt[slot].nRays[1][0];
-    const uint32_t n = nKind1 + b.cnt[slot].nRays[2][0];
-    if ((uint32_t)blockIdx.x * 256u >= n) return;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int budget = (n >> budgetShift) < (uint32_t)budgetMin ? budgetMin : ((n >> budgetShift) > 1024u ? 1024 : (int)(n >> budgetShift));
-    const int* __restrict__ suspIn = b.susp[parity ^ 1];
-    int* __restrict__ suspOut = b.susp[parity];
-    const uint32_t kChunk = (n >> chunkShift) < 64u ? 64u : ((n >> chunkShift) > 256u ? 256u : (n >> chunkShift));
-    sC[t] = make_int4(kFree, 0, 0, -1);
-    if (t == 0) { sQ[0] = 0; sQ[1] = 0; sQ[2] = blockIdx.x % kWfShards; sQ[3] = 0; sQ[4] = 0; sQ[5] = 0xffffffffu; }
-    __syncthreads();
-    const unsigned long long below = (1ull << lane) - 1ull;
-    int* const ovfBase = b.ovf + (size_t)blockIdx.x * 256;
-
-    // stack access of slot s
-    auto push = [&](int s, int& sp, int r) { if (sp < kWfLdsStack) sStack[sp][s] = r; else ovfBase[(size_t)(sp - kWfLdsStack) * ovfStride + s] = r; sp++; };
-    auto pop = [&](int s, int& sp) { sp--; return (sp < kWfLdsStack) ? sStack[sp][s] : ovfBase[(size_t)(sp - kWfLdsStack) * ovfStride + s]; };
-    // a ray that has nothing left to visit: spheres, result, slot free (RayCast tail, CudaUtil.cuh:137-145)
-    auto finish = [&](int s, const f3& org, float bestT, int bestPrim) {
-        const float4 e = sE[s];
-        const int2 d = sD[s];
-        const f3 dir(e.x, e.y, e.z);
-        for (int k = 0; k < sc.n_spheres; k++) {
-            const float4 c = sc.spheres[4 * k];
-            float root;
-            if (sphere_root(f3(c.x, c.y, c.z), c.w, org, dir, bestT, root)) { bestT = root; bestPrim = sc.n_tris + k; }
-        }
-        const int kind = d.y & 3;
-        (kind == 0 ? b.hit[0] : (kind == 1 ? b.hit[1] : b.hit[2]))[d.x] = make_float2(bestT, __int_as_float(bestPrim));
-    };
-
-    for (;;) {
-        // ---- what does my own slot need next? ----
-        const int myCur = sC[t].x;
-        const bool isNode = myCur >= 0, isFree = myCur == kFree, isTri = !isNode && !isFree;
-        const unsigned long long mN = __ballot(isNode), mT = __ballot(isTri), mF = __ballot(isFree);
-        if (lane == 0) { sCnt[0][wave] = __builtin_popcountll(mN); sCnt[1][wave] = __builtin_popcountll(mT); sCnt[2][wave] = __builtin_popcountll(mF); }
-        __syncthreads();
-        uint32_t tot[3], base[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            uint32_t acc = 0, bs = 0;
-#pragma unroll
-            for (int w = 0; w < 4; w++) { const uint32_t c = sCnt[k][w]; if (w < wave) bs += c; acc += c; }
-            tot[k] = acc; base[k] = bs;
-        }
-        if (isNode) sList[0][base[0] + __builtin_popcountll(mN & below)] = (unsigned char)t;
-        else if (isTri) sList[1][base[1] + __builtin_popcountll(mT & below)] = (unsigned char)t;
-        else sList[2][base[2] + __builtin_popcountll(mF & below)] = (unsigned char)t;
-        const bool exhausted = sQ[4] != 0u;
-        if (tot[0] + tot[1] == 0u && exhausted) break;      // uniform over the workgroup
-        __syncthreads();
-        const int Wn = (int)((tot[0] + 63u) >> 6);
-        int Wt = (int)((tot[1] + 63u) >> 6); if (Wt > 4 - Wn) Wt = 4 - Wn;
-
-        if (wave < Wn) {
-            // ================= node steps =================
-            const uint32_t idx = (uint32_t)wave * 64u + lane;
-            if (idx < tot[0]) {
-                const int s = sList[0][idx];
-                const float4 a = sA[s], bb = sB[s];
-                int4 c = sC[s];
-                int2 d = sD[s];
-                const f3 org(a.x, a.y, a.z), inv(bb.x, bb.y, bb.z);
-                float bestT = a.w; const float cscale = bb.w;
-                int cur = c.x, sp = c.y, pend = c.z, bestPrim = c.w;
-                int steps = d.y >> 3;
-                bool live = true;
-                if (steps >= budget) {
-                    // node budget spent: suspend (or, if the pool is full, carry on)
-                    const uint32_t rec = atomicAdd(&b.cnt[slot].nSusp, 1u);
-                    if (rec < b.suspCap) {
-                        int* r = suspOut + (size_t)rec * kSuspInts;
-                        if (pend != 0) { push(s, sp, pend); pend = 0; }
-                        r[0] = cur; r[1] = sp; r[2] = __float_as_int(bestT); r[3] = bestPrim;
-                        for (int k = 0; k < sp; k++) r[4 + k] = (k < kWfLdsStack) ? sStack[k][s] : ovfBase[(size_t)(k - kWfLdsStack) * ovfStride + s];
-                        const int kind = d.y & 3;
-                        (kind == 0 ? b.hit[0] : (kind == 1 ? b.hit[1] : b.hit[2]))[d.x] = make_float2(bestT, __int_as_float(-2 - (int)rec));
-                        sC[s] = make_int4(kFree, 0, 0, -1);
-                        live = false;
-                    } else {
-                        steps = -(1 << 24);
-                    }
-                }
-                if (live) {
-                    steps++;
-                    const uint4* np = sc.quad + 4 * (size_t)cur;
-                    const uint4 n0 = np[0], n1 = np[1], n2 = np[2];
-                    const uint2 n3 = *(const uint2*)(np + 3);
-                    const int eb = (int)n0.w;
-                    const float Ax = __builtin_ldexpf(inv.x, (int)(signed char)(eb & 0xff));
-                    const float Ay = __builtin_ldexpf(inv.y, (int)(signed char)((eb >> 8) & 0xff));
-                    const float Az = __builtin_ldexpf(inv.z, (int)(signed char)((eb >> 16) & 0xff));
-                    const float Bx = (__uint_as_float(n0.x) - org.x) * inv.x;
-                    const float By = (__uint_as_float(n0.y) - org.y) * inv.y;
-                    const float Bz = (__uint_as_float(n0.z) - org.z) * inv.z;
-                    const float kSl = 9.5367431640625e-7f;                           // 2^-20
-                    const float sx = (__builtin_fabsf(Bx) + 255.f * __builtin_fabsf(Ax)) * kSl;
-                    const float sy = (__builtin_fabsf(By) + 255.f * __builtin_fabsf(Ay)) * kSl;
-                    const float sz = (__builtin_fabsf(Bz) + 255.f * __builtin_fabsf(Az)) * kSl;
-                    const float Bnx = Bx - sx, Bfx = Bx + sx, Bny = By - sy, Bfy = By + sy, Bnz = Bz - sz, Bfz = Bz + sz;
-                    const bool px = inv.x >= 0.f, py = inv.y >= 0.f, pz = inv.z >= 0.f;
-                    const uint32_t nqx = px ? n2.x : n2.w, fqx = px ? n2.w : n2.x;
-                    const uint32_t nqy = py ? n2.y : n3.x, fqy = py ? n3.x : n2.y;
-                    const uint32_t nqz = pz ? n2.z : n3.y, fqz = pz ? n3.y : n2.z;
-                    const float cullT = bestT * cscale;
-                    int key[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const float tnx = __builtin_fmaf((float)((nqx >> (8 * k)) & 0xffu), Ax, Bnx);
-                        const float tny = __builtin_fmaf((float)((nqy >> (8 * k)) & 0xffu), Ay, Bny);
-                        const float tnz = __builtin_fmaf((float)((nqz >> (8 * k)) & 0xffu), Az, Bnz);
-                        const float tfx = __builtin_fmaf((float)((fqx >> (8 * k)) & 0xffu), Ax, Bfx);
-                        const float tfy = __builtin_fmaf((float)((fqy >> (8 * k)) & 0xffu), Ay, Bfy);
-                        const float tfz = __builtin_fmaf((float)((fqz >> (8 * k)) & 0xffu), Az, Bfz);
-                        const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.f));
-                        const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, cullT));
-                        key[k] = (tn <= tf) ? ((__float_as_int(tn) & ~3) | k) : 0x7fffffff;
-                    }
-                    const int refs[4] = {(int)n1.x, (int)n1.y, (int)n1.z, (int)n1.w};
-                    int k0 = min(key[0], key[1]), k1 = max(key[0], key[1]), k2 = min(key[2], key[3]), k3 = max(key[2], key[3]);
-                    { const int a0 = min(k0, k2), a2 = max(k0, k2), a1 = min(k1, k3), a3 = max(k1, k3); k0 = a0; k3 = a3; k1 = min(a1, a2); k2 = max(a1, a2); }
-                    auto ref_of = [&](int k) { const int i = k & 3; return i == 0 ? refs[0] : (i == 1 ? refs[1] : (i == 2 ? refs[2] : refs[3])); };
-                    if (k0 != 0x7fffffff) {
-                        if (k3 != 0x7fffffff) push(s, sp, ref_of(k3));
-                        if (k2 != 0x7fffffff) push(s, sp, ref_of(k2));
-                        if (k1 != 0x7fffffff) push(s, sp, ref_of(k1));
-                        cur = ref_of(k0);
-                    } else if (sp == 0) {
-                        cur = kDone;
-                    } else {
-                        cur = pop(s, sp);
-                    }
-                    if (cur < 0 && cur != kDone && pend == 0) {
-                        pend = cur;
-                        if (sp == 0) cur = kDone; else cur = pop(s, sp);
-                    }
-                    if (cur == kDone && pend == 0) {
-                        finish(s, org, bestT, bestPrim);
-                        sC[s] = make_int4(kFree, 0, 0, -1);
-                    } else {
-                        // a slot whose ray only has a parked leaf left (cur == kDone, pend != 0) reads as "triangle work": cur < 0 and not kFree
-                        sC[s] = make_int4(cur, sp, pend, bestPrim);
-                        sD[s].y = (d.y & 7) | (steps << 3);
-                    }
-                }
-            }
-        } else if (wave < Wn + Wt) {
-            // ================= triangle tests =================
-            const uint32_t idx = (uint32_t)(wave - Wn) * 64u + lane;
-            if (idx < tot[1]) {
-                const int s = sList[1][idx];
-                const float4 a = sA[s], bb = sB[s], e = sE[s];
-                int4 c = sC[s];
-                const int2 d = sD[s];
-                const f3 org(a.x, a.y, a.z), inv(bb.x, bb.y, bb.z), dir(e.x, e.y, e.z);
-                float bestT = a.w;
-                int cur = c.x, sp = c.y, pend = c.z, bestPrim = c.w;
-                const bool degenerate = (d.y & 4) != 0;
-                const int code = ~pend, first = code >> 3, cnt = code & 7;
-                pend = 0;
-                if (cnt > 0) {
-                    tri_test_pair(sc, first, cnt > 1, org, dir, inv, degenerate, bestT, bestPrim);
-                    if (bestPrim >= 0 && bestT < e.w) { cur = kDone; sp = 0; }          // shadow ray: any occluder in front of the light will do
-                    else if (cnt > 2) pend = ~(((first + 2) << 3) | (cnt - 2));
-                }
-                if (pend == 0 && cur < 0 && cur != kDone) {
-                    pend = cur;
-                    if (sp == 0) cur = kDone; else cur = pop(s, sp);
-                }
-                if (cur == kDone && pend == 0) {
-                    finish(s, org, bestT, bestPrim);
-                    sC[s] = make_int4(kFree, 0, 0, -1);
-                } else {
-                    sA[s].w = bestT;
-                    sC[s] = make_int4(cur, sp, pend, bestPrim);
-                }
-            }
-        } else if (wave == Wn + Wt && !exhausted && (tot[2] >= (uint32_t)refillMin || tot[0] + tot[1] < 64u)) {
-            // ================= refill: one wave hands new rays to free slots =================
-            uint32_t chunkPos = sQ[0], chunkEnd = sQ[1], seenLeft = sQ[5];
-            int shard = (int)sQ[2], shardsTried = (int)sQ[3];
-            bool exh = false;
-            uint32_t cntShard = 0;
-            if (chunkPos == chunkEnd) {
-                for (;;) {
-                    const uint32_t rounds = n / (kShardBlock * kWfShards), rem = n % (kShardBlock * kWfShards);
-                    const uint32_t part = rem > (uint32_t)shard * kShardBlock ? rem - (uint32_t)shard * kShardBlock : 0u;
-                    cntShard = rounds * kShardBlock + (part < kShardBlock ? part : kShardBlock);
-                    uint32_t want = seenLeft >> guideShift;
-                    want = want < 64u ? 64u : (want > kChunk ? kChunk : want);
-                    uint32_t start = 0;
-                    if (lane == 0) start = atomicAdd(&b.cnt[slot].head[shard].v, want);
-                    start = __builtin_amdgcn_readfirstlane(start);
-                    if (start < cntShard) { chunkPos = start; chunkEnd = (cntShard - start > want) ? start + want : cntShard; seenLeft = cntShard - start; break; }
-                    seenLeft = 0xffffffffu;
-                    shard = (shard + 1) % kWfShards;
-                    if (++shardsTried >= kWfShards) { exh = true; break; }
-                }
-            }
-            if (!exh) {
-                const uint32_t avail = chunkEnd - chunkPos;
-                uint32_t take = tot[2] < 64u ? tot[2] : 64u;
-                if (take > avail) take = avail;
-                if ((uint32_t)lane < take) {
-                    const int s = sList[2][lane];
-                    const uint32_t j = chunkPos + (uint32_t)lane;
-                    const uint32_t q = ((j / kShardBlock) * kWfShards + (uint32_t)shard) * kShardBlock + (j % kShardBlock);
-                    const int kind = q < nPath ? 0 : (q < nKind1 ? 1 : 2);
-                    const uint32_t sid = kind == 0 ? b.rq[0][q] : (kind == 1 ? b.rq[1][q - nPath] : b.rq[2][q - nKind1]);
-                    const float4 o = (kind == 0 ? b.ray_o[0] : (kind == 1 ? b.ray_o[1] : b.ray_o[2]))[sid];
-                    const float4 dd = (kind == 0 ? b.ray_d[0] : (kind == 1 ? b.ray_d[1] : b.ray_d[2]))[sid];
-                    const f3 dir(dd.x, dd.y, dd.z);
-                    f3 inv(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);                       // inv(), CudaUtil.cuh:60-63
-                    const float L = __builtin_sqrtf(inv.x * inv.x + inv.y * inv.y + inv.z * inv.z);
-                    const bool degenerate = !(L < __builtin_inff());
-                    float cscale;
-                    if (!degenerate) {
-                        inv = inv / L;                                                   // Normalize(inv(dir)), :70
-                        cscale = __builtin_amdgcn_rcpf(L) * 1.0000019f;
-                    } else {
-                        inv.x = (__builtin_fabsf(inv.x) <= 1e30f) ? inv.x : __builtin_copysignf(1e30f, dir.x);
-                        inv.y = (__builtin_fabsf(inv.y) <= 1e30f) ? inv.y : __builtin_copysignf(1e30f, dir.y);
-                        inv.z = (__builtin_fabsf(inv.z) <= 1e30f) ? inv.z : __builtin_copysignf(1e30f, dir.z);
-                        cscale = 1.0000019f;
-                    }
-                    const float stopBelow = kind != 0 ? dd.w : -__builtin_inff();
-                    const float2 prev = (kind == 0 ? b.hit[0] : (kind == 1 ? b.hit[1] : b.hit[2]))[sid];
-                    const int pp = __float_as_int(prev.y);
-                    int cur = 0, sp = 0, bestPrim = -1; float bestT = o.w;
-                    if (pp <= -2) {
-                        const int* rec = suspIn + (size_t)(-2 - pp) * kSuspInts;
-                        cur = rec[0]; sp = rec[1]; bestT = __int_as_float(rec[2]); bestPrim = rec[3];
-                        for (int k = 0; k < sp; k++) {
-                            const int v = rec[4 + k];
-                            if (k < kWfLdsStack) sStack[k][s] = v; else ovfBase[(size_t)(k - kWfLdsStack) * ovfStride + s] = v;
-                        }
-                    }
-                    sA[s] = make_float4(o.x, o.y, o.z, bestT);
-                    sB[s] = make_float4(inv.x, inv.y, inv.z, cscale);
-                    sE[s] = make_float4(dir.x, dir.y, dir.z, stopBelow);
-                    sD[s] = make_int2((int)sid, kind | (degenerate ? 4 : 0));
-                    sC[s] = make_int4(cur, sp, 0, bestPrim);
-                }
-                chunkPos += take;
-            }
-            if (lane == 0) { sQ[0] = chunkPos; sQ[1] = chunkEnd; sQ[2] = (uint32_t)shard; sQ[3] = (uint32_t)shardsTried; sQ[4] = exh ? 1u : 0u; sQ[5] = seenLeft; }
-        }
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------
 // wf_shade: one thread per live stream, one bounce.
 // ---------------------------------------------------------------------------------------
 template <int WAVES>
@@ -943,9 +664,6 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     static const int refillMin = getenv("PTAMD_RF") ? atoi(getenv("PTAMD_RF")) : kWfRefill;     // idle lanes that trigger a refill
     static const int triTrig = getenv("PTAMD_TT") ? atoi(getenv("PTAMD_TT")) : 64;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
-    static const bool wgTrace = getenv("PTAMD_WG") && atoi(getenv("PTAMD_WG")) != 0;        // experiment: wg_trace instead of wf_trace
-    static const int wgRefill = (getenv("PTAMD_WGR") && atoi(getenv("PTAMD_WGR")) >= 1) ? atoi(getenv("PTAMD_WGR")) : 48;
-    static const int wgBlocks = (getenv("PTAMD_WGB") && atoi(getenv("PTAMD_WGB")) >= 1) ? atoi(getenv("PTAMD_WGB")) : 1024;
     static const int topNodes = getenv("PTAMD_TOP") ? atoi(getenv("PTAMD_TOP")) : kTopNodes;      // quad nodes staged in LDS (0 = none)
     static const bool traceStatFull = getenv("PTAMD_TSTAT") && atoi(getenv("PTAMD_TSTAT")) == 1;      // 1: trip counters too (slower build); 2: timeline only
     int it = 0;
@@ -958,8 +676,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
             const bool timed = trace_ev && it < trace_ev_pairs;
             if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
-            if (wgTrace && !traceStat) hipLaunchKernelGGL(wg_trace, dim3(nb < wgBlocks ? nb : wgBlocks), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, wgRefill);
-            else if (traceStat && traceStatFull) hipLaunchKernelGGL(wf_trace<1>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
+            if (traceStat && traceStatFull) hipLaunchKernelGGL(wf_trace<1>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
             else if (traceStat) hipLaunchKernelGGL(wf_trace<2>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
             else hipLaunchKernelGGL(wf_trace<0>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, 0);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
