@@ -445,294 +445,6 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
 }
 
 // ---------------------------------------------------------------------------------------
-// wg_trace (experiment, PTAMD_WG=1): the rays of a workgroup pooled in LDS, dense node / triangle waves.
-// Second version: 88-byte slots (7 workgroups per CU), ONE barrier per round (the three work lists are double-buffered and
-// appended to with wave-aggregated LDS atomics while the round runs), direction and shadow threshold re-read from the ray arrays.
-// ---------------------------------------------------------------------------------------
-constexpr int kFree = (int)0x80000001;      // slot state: holds no ray
-constexpr int kWgStack = 7;                 // stack entries per slot kept in LDS (deeper ones go to the global overflow array: 0.6 % of node steps)
-#ifndef WG_WAVES
-#define WG_WAVES 7
-#endif
-__global__ __launch_bounds__(256, WG_WAVES)
-void wg_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift, int refillMin)
-{
-    __shared__ float4 sA[256];              // org.xyz | closest t
-    __shared__ float4 sB[256];              // inv.xyz | cscale
-    __shared__ int4 sC[256];                // cur | sp + (kind << 8) + (degenerate << 10) + (steps << 11) | pend | closest prim
-    __shared__ uint32_t sSid[256];
-    __shared__ int sStack[kWgStack][256];
-    __shared__ unsigned char sList[2][3][256];
-    __shared__ uint32_t sCnt[3][4];
-    __shared__ uint32_t sQ[8];              // chunkPos, chunkEnd, shard, shardsTried, exhausted, seenLeft
-    const uint32_t nPath = b.cnt[slot].nRays[0][0];
-    const uint32_t nKind1 = nPath + b.cnt[slot].nRays[1][0];
-    const uint32_t n = nKind1 + b.cnt[slot].nRays[2][0];
-    if ((uint32_t)blockIdx.x * 256u >= n) return;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int budget = (n >> budgetShift) < (uint32_t)budgetMin ? budgetMin : ((n >> budgetShift) > 1024u ? 1024 : (int)(n >> budgetShift));
-    const int* __restrict__ suspIn = b.susp[parity ^ 1];
-    int* __restrict__ suspOut = b.susp[parity];
-    const uint32_t kChunk = (n >> chunkShift) < 64u ? 64u : ((n >> chunkShift) > 256u ? 256u : (n >> chunkShift));
-    sC[t] = make_int4(kFree, 0, 0, -1);
-    sList[0][2][t] = (unsigned char)t;
-    if (t < 4) { sCnt[0][t] = (t == 2) ? 256u : 0u; sCnt[1][t] = 0u; sCnt[2][t] = 0u; }
-    if (t == 0) { sQ[0] = 0; sQ[1] = 0; sQ[2] = blockIdx.x % kWfShards; sQ[3] = 0; sQ[4] = 0; sQ[5] = 0xffffffffu; }
-    __syncthreads();
-    const unsigned long long below = (1ull << lane) - 1ull;
-    int* const ovfBase = b.ovf + (size_t)blockIdx.x * 256;
-
-    auto push = [&](int s, int& sp, int r) { if (sp < kWgStack) sStack[sp][s] = r; else ovfBase[(size_t)(sp - kWgStack) * ovfStride + s] = r; sp++; };
-    auto pop = [&](int s, int& sp) { sp--; return (sp < kWgStack) ? sStack[sp][s] : ovfBase[(size_t)(sp - kWgStack) * ovfStride + s]; };
-    auto finish = [&](int s, const f3& org, float bestT, int bestPrim, int kind) {
-        const uint32_t sid = sSid[s];
-        if (sc.n_spheres > 0) {
-            const float4 dd = (kind == 0 ? b.ray_d[0] : (kind == 1 ? b.ray_d[1] : b.ray_d[2]))[sid];
-            const f3 dir(dd.x, dd.y, dd.z);
-            for (int k = 0; k < sc.n_spheres; k++) {
-                const float4 c = sc.spheres[4 * k];
-                float root;
-                if (sphere_root(f3(c.x, c.y, c.z), c.w, org, dir, bestT, root)) { bestT = root; bestPrim = sc.n_tris + k; }
-            }
-        }
-        (kind == 0 ? b.hit[0] : (kind == 1 ? b.hit[1] : b.hit[2]))[sid] = make_float2(bestT, __int_as_float(bestPrim));
-    };
-
-    for (int r = 0;; r++) {
-        const int cb = r % 3, nb = (r + 1) % 3, zb = (r + 2) % 3, lb = r & 1, nl = lb ^ 1;
-        const uint32_t nN = sCnt[cb][0], nT = sCnt[cb][1], nF = sCnt[cb][2];
-        if (t < 3) sCnt[zb][t] = 0u;
-        const bool exhausted = sQ[4] != 0u;
-        if (nN + nT == 0u && exhausted) break;      // uniform over the workgroup
-        // wave-aggregated append of slot `s` to next round's list `type` (called by whole waves)
-        auto append = [&](bool want, int type, int s) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const unsigned long long m = __ballot(want && type == k);
-                if (m != 0ull) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&sCnt[nb][k], (uint32_t)__builtin_popcountll(m));
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (want && type == k) sList[nl][k][base + (uint32_t)__builtin_popcountll(m & below)] = (unsigned char)s;
-                }
-            }
-        };
-        int Wn = (int)((nN + 63u) >> 6); if (Wn > 4) Wn = 4;
-        int Wt = (int)((nT + 63u) >> 6); if (Wt > 4 - Wn) Wt = 4 - Wn;
-        const bool wantRefill = !exhausted && nF > 0u && (nF >= (uint32_t)refillMin || nN + nT < 128u);
-        const int refillWave = (Wn + Wt < 4 && wantRefill) ? Wn + Wt : -1;
-        bool mine = false; int newType = 0, s = 0;
-        uint32_t freeDone = 0;              // free-list entries this wave consumed (refill wave only)
-
-        if (wave < Wn) {
-            // ================= node steps =================
-            const uint32_t idx = (uint32_t)wave * 64u + lane;
-            if (idx < nN) {
-                s = sList[lb][0][idx]; mine = true;
-                const float4 a = sA[s], bb = sB[s];
-                const int4 c = sC[s];
-                const f3 org(a.x, a.y, a.z), inv(bb.x, bb.y, bb.z);
-                float bestT = a.w; const float cscale = bb.w;
-                int cur = c.x, sp = c.y & 0xff, pend = c.z, bestPrim = c.w;
-                const int kd = c.y & 0x700;          // kind and degenerate bits
-                int steps = c.y >> 11;
-                bool live = true;
-                if (steps >= budget) {
-                    const uint32_t rec = atomicAdd(&b.cnt[slot].nSusp, 1u);
-                    if (rec < b.suspCap) {
-                        int* rr = suspOut + (size_t)rec * kSuspInts;
-                        if (pend != 0) { push(s, sp, pend); pend = 0; }
-                        rr[0] = cur; rr[1] = sp; rr[2] = __float_as_int(bestT); rr[3] = bestPrim;
-                        for (int k = 0; k < sp; k++) rr[4 + k] = (k < kWgStack) ? sStack[k][s] : ovfBase[(size_t)(k - kWgStack) * ovfStride + s];
-                        const int kind = (kd >> 8) & 3;
-                        (kind == 0 ? b.hit[0] : (kind == 1 ? b.hit[1] : b.hit[2]))[sSid[s]] = make_float2(bestT, __int_as_float(-2 - (int)rec));
-                        sC[s] = make_int4(kFree, 0, 0, -1);
-                        newType = 2; live = false;
-                    } else {
-                        steps = -(1 << 18);
-                    }
-                }
-                if (live) {
-                    steps++;
-                    const uint4* np = sc.quad + 4 * (size_t)cur;
-                    const uint4 n0 = np[0], n1 = np[1], n2 = np[2];
-                    const uint2 n3 = *(const uint2*)(np + 3);
-                    const int eb = (int)n0.w;
-                    const float Ax = __builtin_ldexpf(inv.x, (int)(signed char)(eb & 0xff));
-                    const float Ay = __builtin_ldexpf(inv.y, (int)(signed char)((eb >> 8) & 0xff));
-                    const float Az = __builtin_ldexpf(inv.z, (int)(signed char)((eb >> 16) & 0xff));
-                    const float Bx = (__uint_as_float(n0.x) - org.x) * inv.x;
-                    const float By = (__uint_as_float(n0.y) - org.y) * inv.y;
-                    const float Bz = (__uint_as_float(n0.z) - org.z) * inv.z;
-                    const float kSl = 9.5367431640625e-7f;                           // 2^-20
-                    const float sx = (__builtin_fabsf(Bx) + 255.f * __builtin_fabsf(Ax)) * kSl;
-                    const float sy = (__builtin_fabsf(By) + 255.f * __builtin_fabsf(Ay)) * kSl;
-                    const float sz = (__builtin_fabsf(Bz) + 255.f * __builtin_fabsf(Az)) * kSl;
-                    const float Bnx = Bx - sx, Bfx = Bx + sx, Bny = By - sy, Bfy = By + sy, Bnz = Bz - sz, Bfz = Bz + sz;
-                    const bool px = inv.x >= 0.f, py = inv.y >= 0.f, pz = inv.z >= 0.f;
-                    const uint32_t nqx = px ? n2.x : n2.w, fqx = px ? n2.w : n2.x;
-                    const uint32_t nqy = py ? n2.y : n3.x, fqy = py ? n3.x : n2.y;
-                    const uint32_t nqz = pz ? n2.z : n3.y, fqz = pz ? n3.y : n2.z;
-                    const float cullT = bestT * cscale;
-                    int key[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const float tnx = __builtin_fmaf((float)((nqx >> (8 * k)) & 0xffu), Ax, Bnx);
-                        const float tny = __builtin_fmaf((float)((nqy >> (8 * k)) & 0xffu), Ay, Bny);
-                        const float tnz = __builtin_fmaf((float)((nqz >> (8 * k)) & 0xffu), Az, Bnz);
-                        const float tfx = __builtin_fmaf((float)((fqx >> (8 * k)) & 0xffu), Ax, Bfx);
-                        const float tfy = __builtin_fmaf((float)((fqy >> (8 * k)) & 0xffu), Ay, Bfy);
-                        const float tfz = __builtin_fmaf((float)((fqz >> (8 * k)) & 0xffu), Az, Bfz);
-                        const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.f));
-                        const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, cullT));
-                        key[k] = (tn <= tf) ? ((__float_as_int(tn) & ~3) | k) : 0x7fffffff;
-                    }
-                    const int refs[4] = {(int)n1.x, (int)n1.y, (int)n1.z, (int)n1.w};
-                    int k0 = min(key[0], key[1]), k1 = max(key[0], key[1]), k2 = min(key[2], key[3]), k3 = max(key[2], key[3]);
-                    { const int a0 = min(k0, k2), a2 = max(k0, k2), a1 = min(k1, k3), a3 = max(k1, k3); k0 = a0; k3 = a3; k1 = min(a1, a2); k2 = max(a1, a2); }
-                    auto ref_of = [&](int k) { const int i = k & 3; return i == 0 ? refs[0] : (i == 1 ? refs[1] : (i == 2 ? refs[2] : refs[3])); };
-                    if (k0 != 0x7fffffff) {
-                        if (k3 != 0x7fffffff) push(s, sp, ref_of(k3));
-                        if (k2 != 0x7fffffff) push(s, sp, ref_of(k2));
-                        if (k1 != 0x7fffffff) push(s, sp, ref_of(k1));
-                        cur = ref_of(k0);
-                    } else if (sp == 0) {
-                        cur = kDone;
-                    } else {
-                        cur = pop(s, sp);
-                    }
-                    if (cur < 0 && cur != kDone && pend == 0) {
-                        pend = cur;
-                        if (sp == 0) cur = kDone; else cur = pop(s, sp);
-                    }
-                    if (cur == kDone && pend == 0) {
-                        finish(s, org, bestT, bestPrim, (kd >> 8) & 3);
-                        sC[s] = make_int4(kFree, 0, 0, -1);
-                        newType = 2;
-                    } else {
-                        sC[s] = make_int4(cur, sp | kd | (steps << 11), pend, bestPrim);
-                        newType = cur >= 0 ? 0 : 1;
-                    }
-                }
-            }
-        } else if (wave < Wn + Wt) {
-            // ================= triangle tests =================
-            const uint32_t idx = (uint32_t)(wave - Wn) * 64u + lane;
-            if (idx < nT) {
-                s = sList[lb][1][idx]; mine = true;
-                const float4 a = sA[s], bb = sB[s];
-                const int4 c = sC[s];
-                const int kind = (c.y >> 8) & 3;
-                const float4 dd = (kind == 0 ? b.ray_d[0] : (kind == 1 ? b.ray_d[1] : b.ray_d[2]))[sSid[s]];
-                const f3 org(a.x, a.y, a.z), inv(bb.x, bb.y, bb.z), dir(dd.x, dd.y, dd.z);
-                const float stopBelow = kind != 0 ? dd.w : -__builtin_inff();
-                float bestT = a.w;
-                int cur = c.x, sp = c.y & 0xff, pend = c.z, bestPrim = c.w;
-                const bool degenerate = (c.y & 0x400) != 0;
-                const int code = ~pend, first = code >> 3, cnt = code & 7;
-                pend = 0;
-                if (cnt > 0) {
-                    tri_test_pair(sc, first, cnt > 1, org, dir, inv, degenerate, bestT, bestPrim);
-                    if (bestPrim >= 0 && bestT < stopBelow) { cur = kDone; sp = 0; }
-                    else if (cnt > 2) pend = ~(((first + 2) << 3) | (cnt - 2));
-                }
-                if (pend == 0 && cur < 0 && cur != kDone) {
-                    pend = cur;
-                    if (sp == 0) cur = kDone; else cur = pop(s, sp);
-                }
-                if (cur == kDone && pend == 0) {
-                    finish(s, org, bestT, bestPrim, kind);
-                    sC[s] = make_int4(kFree, 0, 0, -1);
-                    newType = 2;
-                } else {
-                    sA[s].w = bestT;
-                    sC[s] = make_int4(cur, (c.y & ~0xff) | sp, pend, bestPrim);
-                    newType = cur >= 0 ? 0 : 1;
-                }
-            }
-        } else if (wave == refillWave) {
-            // ================= refill: this wave hands new rays to free slots =================
-            uint32_t chunkPos = sQ[0], chunkEnd = sQ[1], seenLeft = sQ[5];
-            int shard = (int)sQ[2], shardsTried = (int)sQ[3];
-            bool exh = false;
-            if (chunkPos == chunkEnd) {
-                for (;;) {
-                    const uint32_t rounds = n / (kShardBlock * kWfShards), rem = n % (kShardBlock * kWfShards);
-                    const uint32_t part = rem > (uint32_t)shard * kShardBlock ? rem - (uint32_t)shard * kShardBlock : 0u;
-                    const uint32_t cntShard = rounds * kShardBlock + (part < kShardBlock ? part : kShardBlock);
-                    uint32_t want = seenLeft >> guideShift;
-                    want = want < 64u ? 64u : (want > kChunk ? kChunk : want);
-                    uint32_t start = 0;
-                    if (lane == 0) start = atomicAdd(&b.cnt[slot].head[shard].v, want);
-                    start = __builtin_amdgcn_readfirstlane(start);
-                    if (start < cntShard) { chunkPos = start; chunkEnd = (cntShard - start > want) ? start + want : cntShard; seenLeft = cntShard - start; break; }
-                    seenLeft = 0xffffffffu;
-                    shard = (shard + 1) % kWfShards;
-                    if (++shardsTried >= kWfShards) { exh = true; break; }
-                }
-            }
-            if (!exh) {
-                const uint32_t avail = chunkEnd - chunkPos;
-                uint32_t take = nF < 64u ? nF : 64u;
-                if (take > avail) take = avail;
-                freeDone = take;
-                if ((uint32_t)lane < take) {
-                    s = sList[lb][2][lane]; mine = true;
-                    const uint32_t j = chunkPos + (uint32_t)lane;
-                    const uint32_t q = ((j / kShardBlock) * kWfShards + (uint32_t)shard) * kShardBlock + (j % kShardBlock);
-                    const int kind = q < nPath ? 0 : (q < nKind1 ? 1 : 2);
-                    const uint32_t sid = kind == 0 ? b.rq[0][q] : (kind == 1 ? b.rq[1][q - nPath] : b.rq[2][q - nKind1]);
-                    const float4 o = (kind == 0 ? b.ray_o[0] : (kind == 1 ? b.ray_o[1] : b.ray_o[2]))[sid];
-                    const float4 dd = (kind == 0 ? b.ray_d[0] : (kind == 1 ? b.ray_d[1] : b.ray_d[2]))[sid];
-                    const f3 dir(dd.x, dd.y, dd.z);
-                    f3 inv(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);                       // inv(), CudaUtil.cuh:60-63
-                    const float L = __builtin_sqrtf(inv.x * inv.x + inv.y * inv.y + inv.z * inv.z);
-                    const bool degenerate = !(L < __builtin_inff());
-                    float cscale;
-                    if (!degenerate) {
-                        inv = inv / L;                                                   // Normalize(inv(dir)), :70
-                        cscale = __builtin_amdgcn_rcpf(L) * 1.0000019f;
-                    } else {
-                        inv.x = (__builtin_fabsf(inv.x) <= 1e30f) ? inv.x : __builtin_copysignf(1e30f, dir.x);
-                        inv.y = (__builtin_fabsf(inv.y) <= 1e30f) ? inv.y : __builtin_copysignf(1e30f, dir.y);
-                        inv.z = (__builtin_fabsf(inv.z) <= 1e30f) ? inv.z : __builtin_copysignf(1e30f, dir.z);
-                        cscale = 1.0000019f;
-                    }
-                    const float2 prev = (kind == 0 ? b.hit[0] : (kind == 1 ? b.hit[1] : b.hit[2]))[sid];
-                    const int pp = __float_as_int(prev.y);
-                    int cur = 0, sp = 0, bestPrim = -1; float bestT = o.w;
-                    if (pp <= -2) {
-                        const int* rec = suspIn + (size_t)(-2 - pp) * kSuspInts;
-                        cur = rec[0]; sp = rec[1]; bestT = __int_as_float(rec[2]); bestPrim = rec[3];
-                        for (int k = 0; k < sp; k++) {
-                            const int v = rec[4 + k];
-                            if (k < kWgStack) sStack[k][s] = v; else ovfBase[(size_t)(k - kWgStack) * ovfStride + s] = v;
-                        }
-                    }
-                    sA[s] = make_float4(o.x, o.y, o.z, bestT);
-                    sB[s] = make_float4(inv.x, inv.y, inv.z, cscale);
-                    sSid[s] = sid;
-                    sC[s] = make_int4(cur, sp | (kind << 8) | (degenerate ? 0x400 : 0), 0, bestPrim);
-                    newType = 0;
-                }
-                chunkPos += take;
-            }
-            if (lane == 0) { sQ[0] = chunkPos; sQ[1] = chunkEnd; sQ[2] = (uint32_t)shard; sQ[3] = (uint32_t)shardsTried; sQ[4] = exh ? 1u : 0u; sQ[5] = seenLeft; }
-        }
-        append(mine, newType, s);
-        // ---- list entries nobody processed this round move on unchanged ----
-        if (wave == refillWave) {
-            for (uint32_t i = freeDone; i < nF; i += 64u) { const bool w = i + lane < nF; append(w, 2, w ? sList[lb][2][i + lane] : 0); }
-        }
-        if (wave == 3) {
-            for (uint32_t i = (uint32_t)Wt * 64u; i < nT; i += 64u) { const bool w = i + lane < nT; append(w, 1, w ? sList[lb][1][i + lane] : 0); }
-            if (refillWave < 0) for (uint32_t i = 0; i < nF; i += 64u) { const bool w = i + lane < nF; append(w, 2, w ? sList[lb][2][i + lane] : 0); }
-        }
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------
 // wf_shade: one thread per live stream, one bounce.
 // ---------------------------------------------------------------------------------------
 template <int WAVES>
@@ -952,9 +664,6 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     static const int refillMin = getenv("PTAMD_RF") ? atoi(getenv("PTAMD_RF")) : kWfRefill;     // idle lanes that trigger a refill
     static const int triTrig = getenv("PTAMD_TT") ? atoi(getenv("PTAMD_TT")) : 64;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
-    static const bool wgTrace = getenv("PTAMD_WG") && atoi(getenv("PTAMD_WG")) != 0;        // experiment: wg_trace instead of wf_trace
-    static const int wgBlocks = (getenv("PTAMD_WGB") && atoi(getenv("PTAMD_WGB")) >= 1) ? atoi(getenv("PTAMD_WGB")) : 256 * WG_WAVES;
-    static const int wgRefill = (getenv("PTAMD_WGR") && atoi(getenv("PTAMD_WGR")) >= 1) ? atoi(getenv("PTAMD_WGR")) : 32;
     static const int topNodes = getenv("PTAMD_TOP") ? atoi(getenv("PTAMD_TOP")) : kTopNodes;      // quad nodes staged in LDS (0 = none)
     static const bool traceStatFull = getenv("PTAMD_TSTAT") && atoi(getenv("PTAMD_TSTAT")) == 1;      // 1: trip counters too (slower build); 2: timeline only
     int it = 0;
@@ -967,8 +676,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
             const bool timed = trace_ev && it < trace_ev_pairs;
             if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
-            if (wgTrace && !traceStat) hipLaunchKernelGGL(wg_trace, dim3(nb < wgBlocks ? nb : wgBlocks), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, wgRefill);
-            else if (traceStat && traceStatFull) hipLaunchKernelGGL(wf_trace<1>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
+            if (traceStat && traceStatFull) hipLaunchKernelGGL(wf_trace<1>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
             else if (traceStat) hipLaunchKernelGGL(wf_trace<2>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
             else hipLaunchKernelGGL(wf_trace<0>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, 0);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
