@@ -52,7 +52,7 @@ static const size_t kCounterBytes = 64 + 2700 * 3 * 8 + 32 * 8 + 2700 * 8 + 64 *
 struct PtScene {
     int device = 0;
     ptd::DevScene dev{};
-    void* d_nodes = nullptr; void* d_quad = nullptr; void* d_tri = nullptr; void* d_leafbox = nullptr;
+    void* d_nodes = nullptr; void* d_quad = nullptr; void* d_tri = nullptr; void* d_tripair = nullptr; void* d_leafbox = nullptr;
     void* d_surf = nullptr;
     void* d_lights = nullptr; void* d_spheres = nullptr;
     unsigned int* d_unit_counter = nullptr;
@@ -221,6 +221,7 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     if ((rc = upload(&sc->d_nodes, accel.wide.data(), accel.wide.size() * 4, sc->bytes)) ||
         (rc = upload(&sc->d_quad, accel.quad.data(), accel.quad.size() * 4, sc->bytes)) ||
         (rc = upload(&sc->d_tri, accel.tri.data(), accel.tri.size() * 4, sc->bytes)) ||
+        (rc = upload(&sc->d_tripair, accel.tripair.data(), accel.tripair.size() * 4, sc->bytes)) ||
         (rc = upload(&sc->d_leafbox, accel.leafbox.data(), accel.leafbox.size() * 4, sc->bytes)) ||
         (rc = upload(&sc->d_surf, surf.data(), surf.size() * 4, sc->bytes)) ||
         (rc = upload(&sc->d_lights, lights.data(), lights.size() * 4, sc->bytes)) ||
@@ -247,6 +248,7 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     if (const char* m = getenv("PTAMD_MODE")) { const int v = atoi(m); if (v >= 0 && v <= 1) sc->mode = v; }
     if (const char* m = getenv("PTAMD_DRAIN")) sc->drain_below = atoi(m);
     sc->dev.nodes = (const float4*)sc->d_nodes; sc->dev.quad = (const uint4*)sc->d_quad; sc->dev.tri = (const float4*)sc->d_tri;
+    sc->dev.tripair = (const float4*)sc->d_tripair;
     sc->dev.leafbox = (const float4*)sc->d_leafbox; sc->dev.surf = (const float4*)sc->d_surf;
     sc->dev.lights = (const float4*)sc->d_lights; sc->dev.spheres = (const float4*)sc->d_spheres;
     sc->dev.n_quad = accel.n_quad;
@@ -260,7 +262,7 @@ void pt_scene_destroy(PtScene* s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* p[] = {s->d_nodes, s->d_quad, s->d_tri, s->d_leafbox, s->d_surf, s->d_lights, s->d_spheres, s->d_unit_counter, s->d_counters};
+    void* p[] = {s->d_nodes, s->d_quad, s->d_tri, s->d_tripair, s->d_leafbox, s->d_surf, s->d_lights, s->d_spheres, s->d_unit_counter, s->d_counters};
     for (void* q : p) if (q) (void)hipFree(q);
     for (int i = 0; i < PtScene::kEvRing; i++) for (int j = 0; j < 2; j++) if (s->ev[i][j]) (void)hipEventDestroy(s->ev[i][j]);
     if (s->h_poll) (void)hipHostFree(s->h_poll);

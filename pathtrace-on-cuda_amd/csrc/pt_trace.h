@@ -160,6 +160,60 @@ PT_DEV void tri_test_pair(const DevScene& sc, int q, bool two, const f3& org, co
     }
 }
 
+// The same two-triangle test on a pair record (pt_device.h: tripair) — the operand pairs come interleaved from memory,
+// so no register moves are needed to form them —, with the per-triangle decisions as straight-line selects:
+//   g_j   triangle j passes the tests of Triangle::hit that do not involve the closest hit so far (det, t >= 0, u, v);
+//   c0    g_0 and t0 / prim0 beat the closest hit on entry;   c1  the same for triangle 1.
+// The reference's leaf box is then evaluated ONCE for most lanes (block A: the box of triangle 0 if c0, else of triangle 1);
+// only a lane where both triangles are candidates goes on to block B, which redoes triangle 1's comparison against
+// the closest hit as triangle 0 left it (in index order, exactly as the loop of tri_test_pair does) and evaluates its box.
+// Every floating-point value is produced by the same IEEE operations as in tri_test.
+PT_DEV bool leaf_box_ok(const DevScene& sc, int leaf, const f3& org, const f3& invD)
+{
+    const float4 l0 = sc.leafbox[2 * leaf]; const float2 l1 = *(const float2*)(sc.leafbox + 2 * leaf + 1);
+    float tn;
+    return box_test(l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, org, invD, __builtin_inff(), tn);
+}
+
+PT_DEV void tri_test_pairrec(const DevScene& sc, int q, bool two, const f3& org, const f3& dir, const f3& invD, bool degenerate,
+                             float& bestT, int& bestPrim)
+{
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const float4* rec = sc.tripair + 6 * (size_t)q;
+    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
+    const float2 r5 = *(const float2*)(rec + 5);
+    const f2v ox = {org.x, org.x}, oy = {org.y, org.y}, oz = {org.z, org.z};
+    const f2v dx = {dir.x, dir.x}, dy = {dir.y, dir.y}, dz = {dir.z, dir.z};
+    const f2v E1x = {r1.z, r1.w}, E1y = {r2.x, r2.y}, E1z = {r2.z, r2.w};
+    const f2v E2x = {r3.x, r3.y}, E2y = {r3.z, r3.w}, E2z = {r4.x, r4.y};
+    const f2v Tx = ox - (f2v){r0.x, r0.y}, Ty = oy - (f2v){r0.z, r0.w}, Tz = oz - (f2v){r1.x, r1.y};
+    const f2v Px = dy * E2z - dz * E2y, Py = -(dx * E2z - dz * E2x), Pz = dx * E2y - dy * E2x;
+    const f2v Qx = Ty * E1z - Tz * E1y, Qy = -(Tx * E1z - Tz * E1x), Qz = Tx * E1y - Ty * E1x;
+    const f2v det = Px * E1x + Py * E1y + Pz * E1z;
+    const f2v tnum = Qx * E2x + Qy * E2y + Qz * E2z;
+    const f2v uu = Px * Tx + Py * Ty + Pz * Tz;
+    const f2v vv = Qx * dx + Qy * dy + Qz * dz;
+    const float t0 = tnum.x * (1.f / det.x), t1 = tnum.y * (1.f / det.y);
+    const int prim0 = __float_as_int(r4.z), prim1 = __float_as_int(r4.w);
+    const bool g0 = !(det.x < kEps) & !(t0 < 0.f) & !((uu.x < 0.f) | (uu.x > det.x)) & !((vv.x < 0.f) | ((vv.x + uu.x) > det.x));
+    const bool g1 = two & !(det.y < kEps) & !(t1 < 0.f) & !((uu.y < 0.f) | (uu.y > det.y)) & !((vv.y < 0.f) | ((vv.y + uu.y) > det.y));
+    const bool c0 = g0 & !(t0 > bestT) & ((t0 < bestT) | (prim0 > bestPrim));
+    const bool c1 = g1 & !(t1 > bestT) & ((t1 < bestT) | (prim1 > bestPrim));
+    if (c0 | c1) {
+        const bool okA = degenerate ? true : leaf_box_ok(sc, __float_as_int(c0 ? r5.x : r5.y), org, invD);
+        if (c0 & c1) {
+            // both: triangle 0 first, then triangle 1 against what it left
+            if (okA) { bestT = t0; bestPrim = prim0; }
+            if (!(t1 > bestT) & ((t1 < bestT) | (prim1 > bestPrim))) {
+                const bool okB = degenerate ? true : leaf_box_ok(sc, __float_as_int(r5.y), org, invD);
+                if (okB) { bestT = t1; bestPrim = prim1; }
+            }
+        } else if (okA) {
+            bestT = c0 ? t0 : t1; bestPrim = c0 ? prim0 : prim1;
+        }
+    }
+}
+
 // Sphere::hit root selection, include/CudaPrimitive.cuh:255-272.
 PT_DEV bool sphere_root(const f3& center, float rad, const f3& org, const f3& dir, float tmax, float& root)
 {

@@ -400,7 +400,11 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 const int code = ~pend, first = code >> 3, cnt = code & 7;
                 pend = 0;
                 if (cnt > 0) {
+#ifdef PT_TRI_LOOP      // A/B build: the pair test with a per-triangle loop on the 48-byte records
                     tri_test_pair(sc, first, cnt > 1, org, dir, inv, degenerate, bestT, bestPrim);
+#else
+                    tri_test_pairrec(sc, first, cnt > 1, org, dir, inv, degenerate, bestT, bestPrim);
+#endif
                     if (bestPrim >= 0 && bestT < stopBelow) { cur = kDone; sp = 0; }          // shadow ray: any occluder in front of the light will do
                     else if (cnt > 2) pend = ~(((first + 2) << 3) | (cnt - 2));
                 }

@@ -180,6 +180,20 @@ void pt_build_accel(const PtBVHNode* rnodes, int n_rnodes, const PtTriangle* tri
         a[8] = t.E2[0]; a[9] = t.E2[1]; a[10] = t.E2[2]; a[11] = 0.f;
     }
 
+    // pair records: record q interleaves the test records of triangles q and q+1 component by component, so that
+    // wf_trace's 2-wide arithmetic reads its operand pairs straight from consecutive registers
+    out.tripair.resize((size_t)n_tris * 24);
+    for (int q = 0; q < n_tris; q++) {
+        const float* a = &out.tri[(size_t)q * 12];
+        const float* c = &out.tri[(size_t)(q + 1 < n_tris ? q + 1 : q) * 12];
+        float* r = &out.tripair[(size_t)q * 24];
+        static const int src[9] = {0, 1, 2, 4, 5, 6, 8, 9, 10};      // V0.xyz E1.xyz E2.xyz
+        for (int k = 0; k < 9; k++) { r[2 * k] = a[src[k]]; r[2 * k + 1] = c[src[k]]; }
+        r[18] = a[3]; r[19] = c[3];      // prim
+        r[20] = a[7]; r[21] = c[7];      // reference leaf
+        r[22] = r[23] = 0.f;
+    }
+
     // wide records: one per interior node, in depth-first order
     std::vector<int> widx(b.nodes.size(), -1);
     int n_wide = 0;
