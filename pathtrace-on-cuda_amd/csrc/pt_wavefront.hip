@@ -369,6 +369,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     const float tfz = __builtin_fmaf((float)((fqz >> (8 * k)) & 0xffu), Az, Bfz);
                     const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.f));
                     const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, cullT));
+#ifdef PT_NODE_KEYSORT      // A/B build: sort keys with the child index in their low bits, select the refs afterwards
                     key[k] = (tn <= tf) ? ((__float_as_int(tn) & ~3) | k) : 0x7fffffff;   // tn >= 0: its bits order like ints
                 }
                 const int refs[4] = {(int)n1.x, (int)n1.y, (int)n1.z, (int)n1.w};
@@ -376,12 +377,24 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 int k0 = min(key[0], key[1]), k1 = max(key[0], key[1]), k2 = min(key[2], key[3]), k3 = max(key[2], key[3]);
                 { const int a0 = min(k0, k2), a2 = max(k0, k2), a1 = min(k1, k3), a3 = max(k1, k3); k0 = a0; k3 = a3; k1 = min(a1, a2); k2 = max(a1, a2); }
                 auto ref_of = [&](int k) { const int i = k & 3; return i == 0 ? refs[0] : (i == 1 ? refs[1] : (i == 2 ? refs[2] : refs[3])); };
+#define PT_REF(k, r) ref_of(k)
+#else
+                    key[k] = (tn <= tf) ? __float_as_int(tn) : 0x7fffffff;   // tn >= 0: its bits order like ints
+                }
+                // sort (entry distance, ref) pairs: 5 compare-exchanges, each one compare + four selects (equal distances: any order will do)
+                int k0 = key[0], k1 = key[1], k2 = key[2], k3 = key[3], r0 = (int)n1.x, r1 = (int)n1.y, r2 = (int)n1.z, r3 = (int)n1.w;
+#define PT_CE(ka, ra, kb, rb) { const bool sw = ka > kb; const int tk = sw ? kb : ka, tr = sw ? rb : ra; kb = sw ? ka : kb; rb = sw ? ra : rb; ka = tk; ra = tr; }
+                PT_CE(k0, r0, k1, r1) PT_CE(k2, r2, k3, r3) PT_CE(k0, r0, k2, r2) PT_CE(k1, r1, k3, r3) PT_CE(k1, r1, k2, r2)
+#undef PT_CE
+#define PT_REF(k, r) (r)
+#endif
                 if (k0 != 0x7fffffff) {
                     // nearest child next; the other hit children go to the stack, farthest first
-                    if (k3 != 0x7fffffff) { const int r = ref_of(k3); if (sp < kWfLdsStack) stack[sp * 64] = r; else ovf[(sp - kWfLdsStack) * ovfStride] = r; sp++; }
-                    if (k2 != 0x7fffffff) { const int r = ref_of(k2); if (sp < kWfLdsStack) stack[sp * 64] = r; else ovf[(sp - kWfLdsStack) * ovfStride] = r; sp++; }
-                    if (k1 != 0x7fffffff) { const int r = ref_of(k1); if (sp < kWfLdsStack) stack[sp * 64] = r; else ovf[(sp - kWfLdsStack) * ovfStride] = r; sp++; }
-                    cur = ref_of(k0);
+                    if (k3 != 0x7fffffff) { const int r = PT_REF(k3, r3); if (sp < kWfLdsStack) stack[sp * 64] = r; else ovf[(sp - kWfLdsStack) * ovfStride] = r; sp++; }
+                    if (k2 != 0x7fffffff) { const int r = PT_REF(k2, r2); if (sp < kWfLdsStack) stack[sp * 64] = r; else ovf[(sp - kWfLdsStack) * ovfStride] = r; sp++; }
+                    if (k1 != 0x7fffffff) { const int r = PT_REF(k1, r1); if (sp < kWfLdsStack) stack[sp * 64] = r; else ovf[(sp - kWfLdsStack) * ovfStride] = r; sp++; }
+                    cur = PT_REF(k0, r0);
+#undef PT_REF
                 } else if (sp == 0) {
                     cur = kDone;
                 } else {
