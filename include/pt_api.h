@@ -251,7 +251,8 @@ PT_API int  pt_dbg_nee(PtScene* s, const float* in5, int32_t n, float* out12);
 PT_API int  pt_dbg_triad(int32_t device, int64_t bytes_per_array, int32_t iters, double* gb_per_s);
 /* Measurement aid: the chip's vector-ALU issue rate, measured — every wave runs a long stream of independent
  * instructions of one kind out of registers (op: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_max3_f32, 3 v_cvt_f32_ubyte1,
- * 4 v_add_u32, 5 v_fma_f64, 6 v_cndmask_b32, 7 v_pk_mul_f32; +16 = lanes 32..63 masked off) at `waves_per_simd`
+ * 4 v_add_u32, 5 v_fma_f64, 6 v_cndmask_b32, 7 v_pk_mul_f32, 8 v_fma_mix_f32, 9 v_cvt_f32_f16, 10 v_perm_b32, 11 v_min_f32,
+ * 12 v_cvt_f32_u32, 13 v_ldexp_f32, 14 v_cmp_le_f32, 15 v_bfe_u32; +16 = lanes 32..63 masked off) at `waves_per_simd`
  * waves per SIMD (1..8).  *wave_insts_per_s = wave-instructions retired per second chip-wide; *clock_ghz = shader
  * clock during the run.  This is the denominator of bench.py's VALU roofline for the traversal kernel. */
 PT_API int  pt_dbg_valu_rate(int32_t device, int32_t op, int32_t waves_per_simd, int32_t iters,

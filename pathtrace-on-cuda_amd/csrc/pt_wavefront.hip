@@ -353,10 +353,21 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 const float sy = (__builtin_fabsf(By) + 255.f * __builtin_fabsf(Ay)) * kSl;
                 const float sz = (__builtin_fabsf(Bz) + 255.f * __builtin_fabsf(Az)) * kSl;
                 const float Bnx = Bx - sx, Bfx = Bx + sx, Bny = By - sy, Bfy = By + sy, Bnz = Bz - sz, Bfz = Bz + sz;
+#ifdef PT_NODE_SELECT      // A/B build: near / far bytes picked with two selects per axis on one compare
                 const bool px = inv.x >= 0.f, py = inv.y >= 0.f, pz = inv.z >= 0.f;
                 const uint32_t nqx = px ? n2.x : n2.w, fqx = px ? n2.w : n2.x;   // lo.x = n2.x, hi.x = n2.w
                 const uint32_t nqy = py ? n2.y : n3.x, fqy = py ? n3.x : n2.y;   // lo.y = n2.y, hi.y = n3.x
                 const uint32_t nqz = pz ? n2.z : n3.y, fqz = pz ? n3.y : n2.z;   // lo.z = n2.z, hi.z = n3.y
+#else
+                // near / far bytes by the sign of the direction, as a masked swap: on this chip a second v_cndmask on the same vcc costs
+                // ~23 clocks (tools/valu_probe.py), xor / and / arithmetic shift ~2.3 each.  (A zero component of either sign gives
+                // A = B = +-0 on that axis: both planes at t = 0, so either assignment is the same test.)
+                const uint32_t mx = (uint32_t)(__float_as_int(inv.x) >> 31), my = (uint32_t)(__float_as_int(inv.y) >> 31), mz = (uint32_t)(__float_as_int(inv.z) >> 31);
+                const uint32_t swx = (n2.x ^ n2.w) & mx, swy = (n2.y ^ n3.x) & my, swz = (n2.z ^ n3.y) & mz;
+                const uint32_t nqx = n2.x ^ swx, fqx = n2.w ^ swx;   // lo.x = n2.x, hi.x = n2.w
+                const uint32_t nqy = n2.y ^ swy, fqy = n3.x ^ swy;   // lo.y = n2.y, hi.y = n3.x
+                const uint32_t nqz = n2.z ^ swz, fqz = n3.y ^ swz;   // lo.z = n2.z, hi.z = n3.y
+#endif
                 const float cullT = bestT * cscale;
                 int key[4];
 #pragma unroll

@@ -428,8 +428,9 @@ def triad_gbps(bytes_per_array=1 << 30, iters=10, device=0):
 
 def valu_rate(op=0, waves_per_simd=4, iters=20000, device=0):
     """Measured VALU issue rate: (wave-instructions per second chip-wide, shader clock in GHz) for one instruction kind
-    (pt_dbg_valu_rate: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_max3_f32, 3 v_cvt_f32_ubyte1, 4 v_add_u32, 5 v_fma_f64, 6 v_cndmask_b32,
-    7 v_pk_mul_f32; +16 = half the lanes masked off)."""
+    or short instruction group (pt_dbg_valu_rate: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_max3_f32, 3 v_cvt_f32_ubyte1, 4 v_add_u32,
+    5 v_fma_f64, 6 v_cndmask_b32, 7 v_pk_mul_f32, 8..67: the table in tools/valu_probe.py; 16 = op 0 with half the lanes masked
+    off, op + 256 = any op with half the lanes masked off)."""
     r, g = C.c_double(0.0), C.c_double(0.0)
     _check(lib().pt_dbg_valu_rate(int(device), int(op), int(waves_per_simd), int(iters), C.byref(r), C.byref(g)), "pt_dbg_valu_rate")
     return float(r.value), float(g.value)
