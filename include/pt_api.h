@@ -265,7 +265,10 @@ PT_API int  pt_last_counters(PtScene* s, int64_t* out8);
  * ~(earliest wave start), ~(earliest time a wave found the ray queue empty; 0 = never), latest wave exit.
  * With PTAMD_TSTAT=1 pt_last_counters returns wf_trace's trip counters instead of the work counters.
  * n_launches = 0: out3n receives 32 int64 instead — the histogram of wave lifetimes in 32-microsecond bins.
- * n_launches = -n: out3n receives n int64 — the number of rays each of the first n launches traced. */
+ * n_launches = -n: out3n receives n int64 — the number of rays each of the first n launches traced.
+ * n_launches = -3000 / -3001 / -3002 (PTAMD_TSTAT=1): 64 int64 histogram of node steps per ray (bins of 4) / 32 int64 histogram of
+ * the stack depth after a node step / 5 int64 shader clocks summed over waves per section of the loop (refill, vote, node step,
+ * triangle step, ray epilogue). */
 PT_API int  pt_dbg_trace_timeline(PtScene* s, int64_t* out3n, int32_t n_launches);
 /* Render path: 1 = queue-driven wavefront pipeline (default: traversal and shading are
  * separate kernels, lanes refill from a ray queue), 0 = the one-kernel state machine.

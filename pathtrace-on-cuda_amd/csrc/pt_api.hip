@@ -47,7 +47,7 @@ void pt_set_error(const char* fmt, ...);   // pt_host.cpp
         }                                                                                   \
     } while (0)
 
-static const size_t kCounterBytes = 64 + 2700 * 3 * 8 + 32 * 8 + 2700 * 8 + 64 * 8 + 32 * 8;   // 8 work counters + diagnostic launch timeline (3 x u64 per wf_trace launch) + wave-lifetime histogram + rays per launch
+static const size_t kCounterBytes = 64 + 2700 * 3 * 8 + 32 * 8 + 2700 * 8 + 64 * 8 + 32 * 8 + 8 * 8;   // 8 work counters + diagnostic launch timeline (3 x u64 per wf_trace launch) + wave-lifetime histogram + rays per launch
 
 struct PtScene {
     int device = 0;
@@ -491,7 +491,13 @@ PT_API int pt_set_drain_threshold(PtScene* s, int32_t live_streams)
 // Ask the next pt_render_tiles on this scene to run the counting build of the kernel.
 int pt_dbg_trace_timeline(PtScene* s, int64_t* out3n, int32_t n_launches)
 {
-    if (!s || !out3n || (n_launches < -2700 && n_launches != -3000 && n_launches != -3001) || n_launches > 2700) { pt_set_error("pt_dbg_trace_timeline: bad arguments"); return PT_ERR_INVALID; }
+    if (!s || !out3n || (n_launches < -2700 && n_launches != -3000 && n_launches != -3001 && n_launches != -3002) || n_launches > 2700) { pt_set_error("pt_dbg_trace_timeline: bad arguments"); return PT_ERR_INVALID; }
+    if (n_launches == -3002) {      // shader clocks per section of wf_trace's loop, summed over waves (5 x int64: refill, vote, node step, triangle step, epilogue), PTAMD_TSTAT=1
+        HIPCHK(hipSetDevice(s->device));
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(out3n, (const char*)s->d_counters + 64 + 2700 * 24 + 32 * 8 + 2700 * 8 + 64 * 8 + 32 * 8, 5 * 8, hipMemcpyDeviceToHost));
+        return PT_OK;
+    }
     if (n_launches == -3001) {      // histogram of the stack depth after each node step (32 x int64), PTAMD_TSTAT=1
         HIPCHK(hipSetDevice(s->device));
         HIPCHK(hipDeviceSynchronize());

@@ -22,9 +22,11 @@
 //      child box = origin + scale * q
 //  tri test record (48 B, 3 x float4):  (V0,prim) (E1,refLeaf) (E2,0) — all a triangle test reads;
 //      prim = index in the reference's order (tie rule, shading), refLeaf = its reference leaf
-//  tri pair record (96 B, 6 x float4), one per triangle q: V0 E1 E2 of triangles q and q+1 interleaved component by
-//      component (V0x[q] V0x[q+1] V0y[q] V0y[q+1] ...: 18 f), prim[q] prim[q+1], refLeaf[q] refLeaf[q+1], 2 unused — wf_trace tests
-//      the two triangles of a leaf with 2-wide arithmetic and reads its operand pairs from consecutive registers
+//  tri pair record (128 B = one cache line, 8 x float4), one per triangle q: V0 E1 E2 of triangles q and q+1 interleaved
+//      component by component (V0x[q] V0x[q+1] V0y[q] V0y[q+1] ...: floats 0..17), prim[q] prim[q+1] (18, 19), then the reference
+//      leaf boxes of the two triangles inline (bMin bMax: floats 20..25 and 26..31) — wf_trace tests the two triangles of a leaf
+//      with 2-wide arithmetic reading its operand pairs from consecutive registers, and the box a candidate hit needs comes from
+//      the line the test has just pulled in (an L1 hit instead of a second trip to L2 / HBM)
 //  reference leaf box (32 B): bMin bMax — read only when Triangle::hit accepts (exact acceptance)
 //  surface record (192 B, 12 x float4), indexed by primitive in the REFERENCE's order — everything
 //      shading needs about a hit triangle in ONE fetch level (no index chasing: the shade kernel
@@ -50,7 +52,7 @@ struct DevScene {
     const float4* nodes;      // traversal tree (SAH over triangles), 4 x float4 per record
     const uint4* quad;        // its 4-wide quantised collapse, 4 x uint4 per record (wf_trace)
     const float4* tri;        // triangle test records in TREE order: (V0,prim) (E1,refLeaf) (E2,0)
-    const float4* tripair;    // pair records for wf_trace, 6 x float4 per triangle q: triangles q and q+1 interleaved (x0 x1 y0 y1 ...), then prims, then leaves
+    const float4* tripair;    // pair records for wf_trace, 8 x float4 per triangle q: triangles q and q+1 interleaved (x0 x1 y0 y1 ...), prims, the two reference leaf boxes
     const float4* leafbox;    // the reference's leaf boxes: 2 x float4 per reference leaf
     const float4* surf;       // surface records, 12 x float4 per primitive (reference order)
     const float4* lights;

@@ -164,13 +164,15 @@ PT_DEV void tri_test_pair(const DevScene& sc, int q, bool two, const f3& org, co
 // so no register moves are needed to form them —, with the per-triangle decisions as straight-line selects:
 //   g_j   triangle j passes the tests of Triangle::hit that do not involve the closest hit so far (det, t >= 0, u, v);
 //   c0    g_0 and t0 / prim0 beat the closest hit on entry;   c1  the same for triangle 1.
-// The reference's leaf box is then evaluated ONCE for most lanes (block A: the box of triangle 0 if c0, else of triangle 1);
+// The reference's leaf box (inline in the pair record) is then evaluated ONCE for most lanes (block A: the box of triangle 0 if c0,
+// else of triangle 1);
 // only a lane where both triangles are candidates goes on to block B, which redoes triangle 1's comparison against
 // the closest hit as triangle 0 left it (in index order, exactly as the loop of tri_test_pair does) and evaluates its box.
 // Every floating-point value is produced by the same IEEE operations as in tri_test.
-PT_DEV bool leaf_box_ok(const DevScene& sc, int leaf, const f3& org, const f3& invD)
+PT_DEV bool pair_box_ok(const float* rec, bool second, const f3& org, const f3& invD)
 {
-    const float4 l0 = sc.leafbox[2 * leaf]; const float2 l1 = *(const float2*)(sc.leafbox + 2 * leaf + 1);
+    const float* bx = rec + (second ? 26 : 20);      // same 128-byte line as the record itself
+    const float4 l0 = *(const float4*)bx; const float2 l1 = *(const float2*)(bx + 4);
     float tn;
     return box_test(l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, org, invD, __builtin_inff(), tn);
 }
@@ -179,9 +181,8 @@ PT_DEV void tri_test_pairrec(const DevScene& sc, int q, bool two, const f3& org,
                              float& bestT, int& bestPrim)
 {
     typedef float f2v __attribute__((ext_vector_type(2)));
-    const float4* rec = sc.tripair + 6 * (size_t)q;
+    const float4* rec = sc.tripair + 8 * (size_t)q;
     const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
-    const float2 r5 = *(const float2*)(rec + 5);
     const f2v ox = {org.x, org.x}, oy = {org.y, org.y}, oz = {org.z, org.z};
     const f2v dx = {dir.x, dir.x}, dy = {dir.y, dir.y}, dz = {dir.z, dir.z};
     const f2v E1x = {r1.z, r1.w}, E1y = {r2.x, r2.y}, E1z = {r2.z, r2.w};
@@ -200,12 +201,12 @@ PT_DEV void tri_test_pairrec(const DevScene& sc, int q, bool two, const f3& org,
     const bool c0 = g0 & !(t0 > bestT) & ((t0 < bestT) | (prim0 > bestPrim));
     const bool c1 = g1 & !(t1 > bestT) & ((t1 < bestT) | (prim1 > bestPrim));
     if (c0 | c1) {
-        const bool okA = degenerate ? true : leaf_box_ok(sc, __float_as_int(c0 ? r5.x : r5.y), org, invD);
+        const bool okA = degenerate ? true : pair_box_ok((const float*)rec, !c0, org, invD);
         if (c0 & c1) {
             // both: triangle 0 first, then triangle 1 against what it left
             if (okA) { bestT = t0; bestPrim = prim0; }
             if (!(t1 > bestT) & ((t1 < bestT) | (prim1 > bestPrim))) {
-                const bool okB = degenerate ? true : leaf_box_ok(sc, __float_as_int(r5.y), org, invD);
+                const bool okB = degenerate ? true : pair_box_ok((const float*)rec, true, org, invD);
                 if (okB) { bestT = t1; bestPrim = prim1; }
             }
         } else if (okA) {

@@ -141,14 +141,15 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
 // closest one.
 // ---------------------------------------------------------------------------------------
 // STAT: a diagnostic build that also counts trips and the lanes they serve (pt_last_counters; PTAMD_TSTAT=1).
-template <int MODE>      // 0 production, 1 trip counters + timeline (PTAMD_TSTAT=1), 2 timeline only (PTAMD_TSTAT=2)
+template <int MODE>      // 0 production, 1 trip counters + histograms + timeline (PTAMD_TSTAT=1), 2 timeline only (PTAMD_TSTAT=2), 3 trip counters + section clocks, no per-step atomics (PTAMD_TSTAT=3)
 __global__ __launch_bounds__(256, TRACE_WAVES)
 void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift, int triTrig, int refillMin,
               int topWant, unsigned long long* stat, int statLaunch)
 {
-    constexpr bool STAT = MODE == 1, timeline = MODE != 0;
+    constexpr bool STAT = MODE == 1 || MODE == 3, HIST = MODE == 1, timeline = MODE != 0;
     const unsigned long long stT0 = timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz
     unsigned long long stTExh = 0;
+    unsigned long long stClk[5] = {0, 0, 0, 0, 0}, stMark = 0;      // STAT: shader clocks in refill / vote + budget / node step / triangle step / ray epilogue
     unsigned long long stNodeTrips = 0, stNodeLanes = 0, stTriTrips = 0, stTriLanes = 0, stRefills = 0, stRefillLanes = 0, stNoRayLanes = 0, stRays = 0;
     __shared__ int lds_stack[4][kWfLdsStack * 64];
     // one queue index space: [0, nPath) path rays, then the shadow rays of kind 1, then those of kind 2
@@ -194,6 +195,8 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
 
     for (;;) {
         // ---- hand new rays to idle lanes (ballot + mbcnt compaction) ----
+        if (STAT) stMark = __builtin_amdgcn_s_memtime();
+#define PT_STCLK(k) if (STAT) { const unsigned long long now = __builtin_amdgcn_s_memtime(); stClk[k] += now - stMark; stMark = now; }
         const unsigned long long idle = __ballot(!hasRay);
         const int nIdle = __builtin_popcountll(idle);
         if (!exhausted && (nIdle >= refillMin)) {
@@ -280,6 +283,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 chunkPos += take;
             }
         }
+        PT_STCLK(0)
         if (__ballot(hasRay) == 0ull) { if (exhausted) break; else continue; }
         if (hasRay) {
             // Only one code path runs per trip: a node step or ONE triangle test per lane (the vote is below).
@@ -318,6 +322,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 if (doNode) { stNodeTrips++; stNodeLanes += nNode; } else { stTriTrips++; stTriLanes += nTri; }
                 stNoRayLanes += 64 - __builtin_popcountll(__ballot(hasRay));
             }
+            PT_STCLK(1)
             if (doNode && cur >= 0) {
                 steps++;
                 // ---- one 4-wide node: conservative slab test of its four quantised child boxes ----
@@ -412,7 +417,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     sp--;
                     cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride];
                 }
-                if (STAT) atomicAdd(&stat[8 + 3 * 2700 + 32 + 2700 + 64 + (sp > 31 ? 31 : sp)], 1ull);      // stack depth after this node step
+                if (HIST) atomicAdd(&stat[8 + 3 * 2700 + 32 + 2700 + 64 + (sp > 31 ? 31 : sp)], 1ull);      // stack depth after this node step
                 if (cur < 0 && cur != kDone && pend == 0) {
                     // park the leaf, carry on with the next stack entry
                     pend = cur;
@@ -439,6 +444,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     else { sp--; cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride]; }
                 }
             }
+            PT_STCLK(doNode ? 2 : 3)
             if (hasRay && cur == kDone && pend == 0) {
                 // spheres, in order, against the triangles' closest t (CudaUtil.cuh:137-145)
                 for (int s = 0; s < sc.n_spheres; s++) {
@@ -448,10 +454,13 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 }
                 (kind == 0 ? b.hit[0] : (kind == 1 ? b.hit[1] : b.hit[2]))[sid] = make_float2(bestT, __int_as_float(bestPrim));
                 hasRay = false;
-                if (STAT) { stRays++; atomicAdd(&stat[8 + 3 * 2700 + 32 + 2700 + (steps >= 252 ? 63 : steps >> 2)], 1ull); }      // node steps of this ray (this launch), bins of 4
+                if (STAT) stRays++;
+                if (HIST) atomicAdd(&stat[8 + 3 * 2700 + 32 + 2700 + (steps >= 252 ? 63 : steps >> 2)], 1ull);      // node steps of this ray (this launch), bins of 4
             }
+            PT_STCLK(4)
         }
     }
+#undef PT_STCLK
     if (timeline) {
         // per-lane ray count -> wave total
         unsigned long long r = stRays;
@@ -468,6 +477,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
             atomicAdd(&hist[dtk < 31 ? dtk : 31], 1ull);
             if (blockIdx.x == 0 && threadIdx.x == 0) hist[32 + statLaunch] = n;      // rays of this launch
             if (STAT) { atomicAdd(&stat[4], stRefills); atomicAdd(&stat[5], stRefillLanes); atomicAdd(&stat[6], stNoRayLanes); atomicAdd(&stat[7], r); }
+            if (STAT) for (int k = 0; k < 5; k++) atomicAdd(&stat[8 + 3 * 2700 + 32 + 2700 + 64 + 32 + k], stClk[k]);
         }
     }
 }
@@ -693,6 +703,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     static const int triTrig = getenv("PTAMD_TT") ? atoi(getenv("PTAMD_TT")) : 64;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
     static const int topNodes = getenv("PTAMD_TOP") ? atoi(getenv("PTAMD_TOP")) : kTopNodes;      // quad nodes staged in LDS (0 = none)
+    static const bool traceStatClk = getenv("PTAMD_TSTAT") && atoi(getenv("PTAMD_TSTAT")) == 3;      // 3: trip counters + section clocks, no histograms
     static const bool traceStatFull = getenv("PTAMD_TSTAT") && atoi(getenv("PTAMD_TSTAT")) == 1;      // 1: trip counters too (slower build); 2: timeline only
     int it = 0;
     int poll = 16;
@@ -704,7 +715,8 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
             const bool timed = trace_ev && it < trace_ev_pairs;
             if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
-            if (traceStat && traceStatFull) hipLaunchKernelGGL(wf_trace<1>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
+            if (traceStat && traceStatClk) hipLaunchKernelGGL(wf_trace<3>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
+            else if (traceStat && traceStatFull) hipLaunchKernelGGL(wf_trace<1>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
             else if (traceStat) hipLaunchKernelGGL(wf_trace<2>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
             else hipLaunchKernelGGL(wf_trace<0>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, 0);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);

@@ -180,18 +180,20 @@ void pt_build_accel(const PtBVHNode* rnodes, int n_rnodes, const PtTriangle* tri
         a[8] = t.E2[0]; a[9] = t.E2[1]; a[10] = t.E2[2]; a[11] = 0.f;
     }
 
-    // pair records: record q interleaves the test records of triangles q and q+1 component by component, so that
-    // wf_trace's 2-wide arithmetic reads its operand pairs straight from consecutive registers
-    out.tripair.resize((size_t)n_tris * 24);
+    // pair records (128 B = one cache line each): record q interleaves the test records of triangles q and q+1 component by
+    // component, so that wf_trace's 2-wide arithmetic reads its operand pairs straight from consecutive registers, and carries
+    // the two reference leaf boxes inline — the box a candidate hit needs is then in the line the test has just pulled in
+    out.tripair.resize((size_t)n_tris * 32);
     for (int q = 0; q < n_tris; q++) {
         const float* a = &out.tri[(size_t)q * 12];
         const float* c = &out.tri[(size_t)(q + 1 < n_tris ? q + 1 : q) * 12];
-        float* r = &out.tripair[(size_t)q * 24];
+        float* r = &out.tripair[(size_t)q * 32];
         static const int src[9] = {0, 1, 2, 4, 5, 6, 8, 9, 10};      // V0.xyz E1.xyz E2.xyz
         for (int k = 0; k < 9; k++) { r[2 * k] = a[src[k]]; r[2 * k + 1] = c[src[k]]; }
         r[18] = a[3]; r[19] = c[3];      // prim
-        r[20] = a[7]; r[21] = c[7];      // reference leaf
-        r[22] = r[23] = 0.f;
+        int la, lc; memcpy(&la, &a[7], 4); memcpy(&lc, &c[7], 4);
+        memcpy(&r[20], &out.leafbox[(size_t)la * 8], 24);      // bMin bMax of triangle q's reference leaf
+        memcpy(&r[26], &out.leafbox[(size_t)lc * 8], 24);      // ... of triangle q+1's
     }
 
     // wide records: one per interior node, in depth-first order

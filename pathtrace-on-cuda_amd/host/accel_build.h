@@ -10,7 +10,7 @@ constexpr int kAccelMaxDepth = 32;       // == ptd::kStackDepth; the builder nev
 struct PtAccel {
     std::vector<float> wide;             // n_wide x 16 floats (two child boxes + two refs)
     std::vector<float> tri;              // n_tris x 12 floats, tree order: (V0,prim) (E1,refLeaf) (E2,0)
-    std::vector<float> tripair;          // n_tris x 24 floats: record q = triangles q and q+1 (the last: q twice) interleaved for wf_trace's 2-wide test (csrc/pt_device.h)
+    std::vector<float> tripair;          // n_tris x 32 floats: record q = triangles q and q+1 (the last: q twice) interleaved for wf_trace's 2-wide test + their two reference leaf boxes (csrc/pt_device.h)
     std::vector<float> leafbox;          // n_leaves x 8 floats: the reference's leaf boxes, verbatim
     std::vector<uint32_t> quad;          // n_quad x 16 dwords: the 4-wide quantised tree (layout: csrc/pt_device.h)
     int n_wide = 0, n_leaves = 0, depth = 0;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Trip statistics of wf_trace (diagnostic build, PTAMD_TSTAT=1): how full the node / triangle trips are."""
 import os, sys
-os.environ["PTAMD_TSTAT"] = "1"
+os.environ.setdefault("PTAMD_TSTAT", "1")      # 3: trip counters + section clocks without the per-step histogram atomics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pathtrace-on-cuda_amd"))
 import numpy as np, torch, ptamd
@@ -41,3 +41,8 @@ hd = np.zeros(32, np.int64)
 ptamd.lib().pt_dbg_trace_timeline(sc._h, hd.ctypes.data_as(C.c_void_p), -3001)
 tot = max(1, int(hd.sum())); cum = np.cumsum(hd[::-1])[::-1] / tot
 print("stack depth after a node step: mean %.2f; fraction of node steps with depth >= N:" % (float((hd * np.arange(32)).sum()) / tot), " ".join("%d:%.2e" % (k, cum[k]) for k in (1, 2, 4, 6, 8, 10, 12, 14, 16, 20)))
+hc = np.zeros(5, np.int64)
+ptamd.lib().pt_dbg_trace_timeline(sc._h, hc.ctypes.data_as(C.c_void_p), -3002)
+tot = max(1, int(hc.sum()))
+print("wave clocks by section of the loop (counting build): refill %.1f%%  vote+budget %.1f%%  node step %.1f%%  triangle step %.1f%%  ray epilogue %.1f%%;  per trip: node %.0f clk, triangle %.0f clk, per refill %.0f clk" %
+      tuple([100.0 * x / tot for x in hc] + [hc[2] / max(nT, 1), hc[3] / max(tT, 1), hc[0] / max(rf, 1)]))
