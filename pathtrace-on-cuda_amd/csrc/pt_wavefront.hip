@@ -167,6 +167,19 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
     const int lane = threadIdx.x & 63;
     int* stack = &lds_stack[threadIdx.x >> 6][lane];
     int* ovf = b.ovf + (blockIdx.x * 256 + threadIdx.x);
+    // Stack entry k of this lane: LDS below kWfLdsStack, global memory above (5e-7 of the node steps).  Written as a plain select of
+    // the two places the compiler merges them into ONE flat_load (LDS through the texture path, waited for with vmcnt(0), i.e. behind
+    // every outstanding store); the empty asm pins the LDS read down as a ds_read of its own.
+#ifdef PT_FLAT_POP      // A/B build
+    auto stack_at = [&](int k) -> int { return (k < kWfLdsStack) ? stack[k * 64] : ovf[(k - kWfLdsStack) * ovfStride]; };
+#else
+    auto stack_at = [&](int k) -> int {
+        int v = stack[(k < kWfLdsStack ? k : 0) * 64];
+        asm volatile("" : "+v"(v));
+        if (k >= kWfLdsStack) v = ovf[(k - kWfLdsStack) * ovfStride];
+        return v;
+    };
+#endif
     // node steps a ray may take in this launch before it is suspended: large launches hide long rays,
     // small (latency-bound) launches must not wait for them
     const int budget = (n >> budgetShift) < (uint32_t)budgetMin ? budgetMin : ((n >> budgetShift) > 1024u ? 1024 : (int)(n >> budgetShift));
@@ -415,14 +428,14 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     cur = kDone;
                 } else {
                     sp--;
-                    cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride];
+                    cur = stack_at(sp);
                 }
                 if (HIST) atomicAdd(&stat[8 + 3 * 2700 + 32 + 2700 + 64 + (sp > 31 ? 31 : sp)], 1ull);      // stack depth after this node step
                 if (cur < 0 && cur != kDone && pend == 0) {
                     // park the leaf, carry on with the next stack entry
                     pend = cur;
                     if (sp == 0) cur = kDone;
-                    else { sp--; cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride]; }
+                    else { sp--; cur = stack_at(sp); }
                 }
             } else if (doTri && hasRay && pend != 0) {
                 // ---- the parked leaf: its (up to) two triangles in one go ----
@@ -441,7 +454,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     // the ray was waiting with a second leaf: park that one, take the next stack entry
                     pend = cur;
                     if (sp == 0) cur = kDone;
-                    else { sp--; cur = (sp < kWfLdsStack) ? stack[sp * 64] : ovf[(sp - kWfLdsStack) * ovfStride]; }
+                    else { sp--; cur = stack_at(sp); }
                 }
             }
             PT_STCLK(doNode ? 2 : 3)
