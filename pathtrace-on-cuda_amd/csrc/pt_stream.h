@@ -193,9 +193,17 @@ PT_DEV bool bounce(const DevScene& sc, const DevParams& prm, int prim, float t, 
 
 // Returns true when the stream has added its last sample to the pixel.  On return st.flags
 // describes the rays to trace next and the ray fields hold them.
-PT_DEV bool shade_step(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const WfBuf& b, uint32_t sid, SState& st,
-                       float2 hitP, float2 hitS, float2 hitA)
+// DEFER (wf_shade): the bounce of round 1 — the first hit of the next sample, needed by the ~quarter of the streams whose path
+// has just ended — is not run here but handed back as a job (prim, t; the stream's rng / toStart are in st), so that the
+// workgroup can run all its round-1 bounces in dense waves (round1_exec below) instead of every wave running the bounce code a
+// second time for a quarter of its lanes.  Same operations on the same stream state in the same order: bit-identical.
+struct Round1Job { bool go; int prim; float t; };
+
+template <bool DEFER>
+PT_DEV bool shade_step_t(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const WfBuf& b, uint32_t sid, SState& st,
+                         float2 hitP, float2 hitS, float2 hitA, Round1Job& job)
 {
+    job.go = false; job.prim = -1; job.t = 0.f;
     const float4* __restrict__ pixPtr = &b.pix[sid];
     const float4* __restrict__ dir0Ptr = &b.dir0[sid];
     float2* __restrict__ hit0Ptr = &b.hit0[sid];
@@ -271,6 +279,7 @@ PT_DEV bool shade_step(const DevScene& sc, const DevCamera& cam, const DevParams
                     st.toStart--;                                            // pathtracer.cu:77-78: next sample
                     st.weight = f3(1.f, 1.f, 1.f); st.radiance = f3(0.f, 0.f, 0.f);
                     st.depth = 0; st.refractCnt = 0; bRefracted = false; cur = true;
+                    if (DEFER) { job.go = true; job.prim = prim; job.t = t; go = false; shCur = false; neeCur = false; pathCur = false; }      // round1_exec sets these three
                 }
             }
         }
@@ -293,6 +302,13 @@ PT_DEV bool shade_step(const DevScene& sc, const DevCamera& cam, const DevParams
     st.flags = (cur ? F_CUR : 0u) | (shCur ? F_SHADOW : 0u) | (neeCur ? F_NEEOK : 0u) | (pathCur ? F_PATH : 0u) |
                (shA ? F_SHADOWA : 0u) | (neeA ? F_NEEOKA : 0u) | (bRefracted ? F_REFR : 0u);
     return !cur && !shA && st.toStart == 0;
+}
+
+PT_DEV bool shade_step(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const WfBuf& b, uint32_t sid, SState& st,
+                       float2 hitP, float2 hitS, float2 hitA)
+{
+    Round1Job job;
+    return shade_step_t<false>(sc, cam, prm, b, sid, st, hitP, hitS, hitA, job);
 }
 
 PT_DEV void load_state(const WfBuf& b, uint32_t sid, SState& st)
@@ -339,6 +355,27 @@ PT_DEV void store_state(const WfBuf& b, uint32_t slot, const SState& st)
         b.ray_o[0][slot] = make_float4(st.pathO.x, st.pathO.y, st.pathO.z, 999999.f);
         b.ray_d[0][slot] = make_float4(st.pathD.x, st.pathD.y, st.pathD.z, -__builtin_inff());
     }
+}
+
+// A deferred round-1 bounce (shade_step_t<true>): the new sample's first bounce at the pixel's cached camera hit, then the
+// stream's state and rays go back to its slot exactly as store_state would have written them from the stream's own lane
+// (pixelColor excepted: the owner lane stores it).  flagsBase: the flag bits that do not depend on this bounce (F_CUR, slot A).
+// Returns bit 0: a path ray was queued, bit 1: a shadow ray was queued.
+PT_DEV uint32_t round1_exec(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const WfBuf& b, uint32_t sid,
+                            const Rng& rng, int toStart, uint32_t flagsBase, int prim, float t)
+{
+    SState st;
+    st.rng = rng; st.toStart = toStart; st.depth = 0; st.refractCnt = 0;
+    st.weight = f3(1.f, 1.f, 1.f); st.radiance = f3(0.f, 0.f, 0.f);
+    st.pixelColor = f3(0.f, 0.f, 0.f); st.pixLoaded = false;
+    st.cosA = 0.f; st.denom = 1.f;
+    const float4 d0 = b.dir0[sid];
+    bool bRefracted = false, neeCur = false, needSh = false;
+    const bool terminate = bounce(sc, prm, prim, t, f3(cam.pos[0], cam.pos[1], cam.pos[2]), f3(d0.x, d0.y, d0.z), st, bRefracted, neeCur, needSh);
+    const bool pathCur = !terminate, shCur = needSh;
+    st.flags = flagsBase | (shCur ? F_SHADOW : 0u) | (neeCur ? F_NEEOK : 0u) | (pathCur ? F_PATH : 0u) | (bRefracted ? F_REFR : 0u);
+    store_state(b, sid, st);
+    return (pathCur ? 1u : 0u) | (shCur ? 2u : 0u);
 }
 
 }  // namespace ptd

@@ -502,16 +502,27 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES * 256, WAVES)
 void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, int slotOut, int slotClear, int listIn)
 {
+    // Round-1 bounces of the workgroup (shade_step_t<true>: the first bounce of the next sample, for the streams whose path has
+    // just ended) are queued here and run by dense waves after a barrier.
+    constexpr int kJobWords = 10;      // sid, rng x0..x4 d, toStart | flagsBase << 16, prim, t
+    __shared__ uint32_t s_job[kJobWords][kShadeThreads];
+    __shared__ uint16_t s_owner[kShadeThreads];      // job -> owner thread
+    __shared__ uint8_t s_res[kShadeThreads];         // owner thread -> result bits of its job
+    __shared__ uint32_t s_njobs;
     const uint32_t nIn = b.cnt[slotIn].nActive;
     if (blockIdx.x == 0) for (int k = threadIdx.x; k < kWfSlotBytes / 4; k += blockDim.x) ((uint32_t*)&b.cnt[slotClear])[k] = 0;
     if ((uint32_t)blockIdx.x * blockDim.x >= nIn) return;
+    if (threadIdx.x == 0) s_njobs = 0;
+    __syncthreads();
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const bool have = idx < nIn;
+    const int lane = threadIdx.x & 63;
     bool alive = false, emit[kRayKinds] = {false, false, false};
     uint32_t sid = 0;
+    Round1Job job; job.go = false; job.prim = -1; job.t = 0.f;
+    SState st;
     if (have) {
         sid = b.active[listIn][idx];
-        SState st;
         const float2 hitP = b.hit[0][sid], hitS = b.hit[1][sid], hitA = b.hit[2][sid];      // same fetch level as the state
         load_state(b, sid, st);
         // a ray of this stream is still being traversed (time-sliced): wait one iteration
@@ -520,9 +531,17 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
         if (pendP <= -2 || pendS <= -2 || pendA <= -2) {
             alive = true; emit[0] = pendP <= -2; emit[1] = pendS <= -2; emit[2] = pendA <= -2;
         } else {
-            const bool done = shade_step(sc, cam, prm, b, sid, st, hitP, hitS, hitA);
+#ifdef PT_SHADE_ROUND1_INLINE      // A/B build: every wave runs its own round-1 bounces
+            const bool done = shade_step_t<false>(sc, cam, prm, b, sid, st, hitP, hitS, hitA, job);
+#else
+            const bool done = shade_step_t<true>(sc, cam, prm, b, sid, st, hitP, hitS, hitA, job);
+#endif
             if (done) {
                 write_mean(b, prm, sid, st);
+            } else if (job.go) {
+                // the rest of this stream's step runs in round1_exec, which stores its state; the pixel sum stays with the owner
+                if (st.pixLoaded) b.pix[sid] = make_float4(st.pixelColor.x, st.pixelColor.y, st.pixelColor.z, 0.f);
+                alive = true; emit[2] = (st.flags & F_SHADOWA) != 0;
             } else {
                 const uint32_t nf = st.flags;
                 store_state(b, sid, st);
@@ -531,6 +550,33 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
             }
         }
     }
+    // queue the round-1 jobs (one LDS atomic per wave)
+    {
+        const unsigned long long m = __ballot(job.go);
+        uint32_t base = 0;
+        if (m != 0ull && lane == 0) base = atomicAdd(&s_njobs, (uint32_t)__builtin_popcountll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (job.go) {
+            const uint32_t j = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            s_job[0][j] = sid; s_job[1][j] = st.rng.x0; s_job[2][j] = st.rng.x1; s_job[3][j] = st.rng.x2; s_job[4][j] = st.rng.x3;
+            s_job[5][j] = st.rng.x4; s_job[6][j] = st.rng.d; s_job[7][j] = (uint32_t)st.toStart | (st.flags << 16);
+            s_job[8][j] = (uint32_t)job.prim; s_job[9][j] = __float_as_uint(job.t);
+            s_owner[j] = (uint16_t)threadIdx.x;
+        }
+    }
+    __syncthreads();
+    {
+        // job j runs on thread (j + rot) mod blockDim: the busy waves of neighbouring workgroups land on different SIMDs
+        const uint32_t nj = s_njobs, rot = (blockIdx.x * 3u % (blockDim.x >> 6)) << 6;
+        const uint32_t j = (threadIdx.x + blockDim.x - rot) % blockDim.x;
+        if (j < nj) {
+            Rng rng; rng.x0 = s_job[1][j]; rng.x1 = s_job[2][j]; rng.x2 = s_job[3][j]; rng.x3 = s_job[4][j]; rng.x4 = s_job[5][j]; rng.d = s_job[6][j];
+            const uint32_t tf = s_job[7][j];
+            s_res[s_owner[j]] = (uint8_t)round1_exec(sc, cam, prm, b, s_job[0][j], rng, (int)(tf & 0xffffu), tf >> 16, (int)s_job[8][j], __uint_as_float(s_job[9][j]));
+        }
+    }
+    __syncthreads();
+    if (job.go) { const uint32_t r = s_res[threadIdx.x]; emit[0] = (r & 1u) != 0; emit[1] = (r & 2u) != 0; }
     const bool e[kLists] = {alive, emit[0], emit[1], emit[2]};
     uint32_t* const c[kLists] = {&b.cnt[slotOut].nActive, &b.cnt[slotOut].nRays[0][0], &b.cnt[slotOut].nRays[1][0], &b.cnt[slotOut].nRays[2][0]};
     uint32_t* const l[kLists] = {b.active[listIn ^ 1], b.rq[0], b.rq[1], b.rq[2]};
