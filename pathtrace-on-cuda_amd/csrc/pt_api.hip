@@ -33,7 +33,7 @@ int ptk_wf_cohorts(size_t nUnits);
 const float* ptk_wf_staging(void* work);
 int ptk_wf_stack_capacity(void);
 hipError_t ptk_wf_render(int, const ptd::DevScene*, const ptd::DevCamera*, const ptd::DevParams*, void*, int, uint32_t*, hipStream_t, hipStream_t*,
-                         hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t*, int*, hipEvent_t*, int, int*, int, void*);
+                         hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t*, int*, hipEvent_t*, int, int*, int, int, void*);
 }
 
 void pt_set_error(const char* fmt, ...);   // pt_host.cpp
@@ -65,6 +65,7 @@ struct PtScene {
     int mode = 1;            // 1 = wavefront pipeline (default), 0 = one-kernel state machine
     uint32_t* h_poll = nullptr;   // pinned, for the pipeline's live-stream count
     int last_iters = 0;
+    int shade_rounds = 1;        // wf_shade: 1 = a stream may start its next sample in the step its path ends, 0 = one bounce per step, -1 = by live-stream count (PTAMD_TRS)
     int drain_below = 0;         // hand the last streams to wf_drain once this few are live (0 = never; measured slower than the tail it replaces)
     // optional per-launch timing of the traversal kernel (pt_enable_trace_timing)
     std::vector<hipEvent_t> trace_ev;
@@ -247,6 +248,7 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     // environment overrides of the per-scene defaults (the same settings have C-ABI setters: pt_set_mode, pt_set_drain_threshold)
     if (const char* m = getenv("PTAMD_MODE")) { const int v = atoi(m); if (v >= 0 && v <= 1) sc->mode = v; }
     if (const char* m = getenv("PTAMD_DRAIN")) sc->drain_below = atoi(m);
+    if (const char* m = getenv("PTAMD_TR")) { const int v = atoi(m); if (v >= -1 && v <= 1) sc->shade_rounds = v; }
     sc->dev.nodes = (const float4*)sc->d_nodes; sc->dev.quad = (const uint4*)sc->d_quad; sc->dev.tri = (const float4*)sc->d_tri;
     sc->dev.tripair = (const float4*)sc->d_tripair;
     sc->dev.leafbox = (const float4*)sc->d_leafbox; sc->dev.surf = (const float4*)sc->d_surf;
@@ -362,7 +364,7 @@ int pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm, float*
         if (kTraceStat) HIPCHK(hipMemsetAsync(s->d_counters, 0, kCounterBytes, stream));
         HIPCHK(ptk_wf_render(s->device, &s->dev, &c, &d, d_work, kTraceBlocks, s->h_poll, stream, s->xstreams,
                              s->ev[slot][0], s->ev[slot][1], s->ev_fork, s->ev_join, &iters,
-                             s->trace_ev.empty() ? nullptr : s->trace_ev.data(), (int)s->trace_ev.size() / 2, s->trace_ev_used, s->drain_below,
+                             s->trace_ev.empty() ? nullptr : s->trace_ev.data(), (int)s->trace_ev.size() / 2, s->trace_ev_used, s->drain_below, s->shade_rounds,
                              kTraceStat ? s->d_counters : nullptr));
         s->last_iters = iters;
         s->ev_count++;
@@ -486,6 +488,12 @@ PT_API int pt_set_drain_threshold(PtScene* s, int32_t live_streams)
 {
     if (!s || live_streams < 0) { pt_set_error("pt_set_drain_threshold: bad argument"); return PT_ERR_INVALID; }
     s->drain_below = live_streams;
+    return PT_OK;
+}
+PT_API int pt_set_shade_rounds(PtScene* s, int32_t mode)
+{
+    if (!s || mode < -1 || mode > 1) { pt_set_error("pt_set_shade_rounds: mode must be -1, 0 or 1"); return PT_ERR_INVALID; }
+    s->shade_rounds = mode;
     return PT_OK;
 }
 // Ask the next pt_render_tiles on this scene to run the counting build of the kernel.

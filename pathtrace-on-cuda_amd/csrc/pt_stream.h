@@ -193,17 +193,10 @@ PT_DEV bool bounce(const DevScene& sc, const DevParams& prm, int prim, float t, 
 
 // Returns true when the stream has added its last sample to the pixel.  On return st.flags
 // describes the rays to trace next and the ray fields hold them.
-// DEFER (wf_shade): the bounce of round 1 — the first hit of the next sample, needed by the ~quarter of the streams whose path
-// has just ended — is not run here but handed back as a job (prim, t; the stream's rng / toStart are in st), so that the
-// workgroup can run all its round-1 bounces in dense waves (round1_exec below) instead of every wave running the bounce code a
-// second time for a quarter of its lanes.  Same operations on the same stream state in the same order: bit-identical.
-struct Round1Job { bool go; int prim; float t; };
-
-template <bool DEFER>
+template <bool TWO>
 PT_DEV bool shade_step_t(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const WfBuf& b, uint32_t sid, SState& st,
-                         float2 hitP, float2 hitS, float2 hitA, Round1Job& job)
+                         float2 hitP, float2 hitS, float2 hitA)
 {
-    job.go = false; job.prim = -1; job.t = 0.f;
     const float4* __restrict__ pixPtr = &b.pix[sid];
     const float4* __restrict__ dir0Ptr = &b.dir0[sid];
     float2* __restrict__ hit0Ptr = &b.hit0[sid];
@@ -242,6 +235,7 @@ PT_DEV bool shade_step_t(const DevScene& sc, const DevCamera& cam, const DevPara
     if (flags & F_PRIMARY) *hit0Ptr = hitP;                                  // the camera ray's hit, shared by every sample
     else if (!(flags & F_PATH) && cur) { add_to_pixel(st.radiance); cur = false; }   // the current sample closed one step ago
 
+    if constexpr (TWO) {
     // ---- c. up to two hits to shade: round 0 the current path's, round 1 the first hit of the next sample ----
 #pragma unroll
     for (int round = 0; round < 2; round++) {
@@ -279,7 +273,6 @@ PT_DEV bool shade_step_t(const DevScene& sc, const DevCamera& cam, const DevPara
                     st.toStart--;                                            // pathtracer.cu:77-78: next sample
                     st.weight = f3(1.f, 1.f, 1.f); st.radiance = f3(0.f, 0.f, 0.f);
                     st.depth = 0; st.refractCnt = 0; bRefracted = false; cur = true;
-                    if (DEFER) { job.go = true; job.prim = prim; job.t = t; go = false; shCur = false; neeCur = false; pathCur = false; }      // round1_exec sets these three
                 }
             }
         }
@@ -299,6 +292,65 @@ PT_DEV bool shade_step_t(const DevScene& sc, const DevCamera& cam, const DevPara
             }
         }
     }
+    } else {
+    // ---- c'. ONE hit to shade per step (TWO = false): the lane continues its current path if it has a path hit, or else
+    // starts the next sample at the pixel's cached camera hit — the same bounce code for both, so a wave runs it once.  A sample
+    // then takes `bounces` steps instead of `bounces - 1`, but every step's dependent chain is one bounce long instead of two.
+    // The operations a stream goes through, and their order, are those of the two-round step; only the step they happen in
+    // differs, so both schedules (and any mix of them) give the same bits. ----
+    {
+        bool go = false, fresh = false;
+        int prim = -1; float t = 0.f;
+        f3 rorg(0.f, 0.f, 0.f), rdir(0.f, 0.f, 1.f);
+        if ((flags & F_PATH) && !(flags & F_PRIMARY)) {
+            prim = __float_as_int(hitP.y); t = hitP.x; rorg = st.pathO; rdir = st.pathD;
+            if (prim < 0) {
+                st.radiance += st.weight * f3(0.1f, 0.1f, 0.1f);               // CudaUtil.cuh:375-379: the path left the scene
+                add_to_pixel(st.radiance);
+                cur = false;
+            } else go = true;
+        }
+        if (!go && (!cur || closing) && st.toStart > 0) {
+            if (closing) {
+                // the closed sample waits in slot A for its shadow ray; the pixel gets it first thing next step
+                b.radA[sid] = make_float4(st.radiance.x, st.radiance.y, st.radiance.z, st.denom);
+                b.wbA[sid] = make_float4(st.wb.x, st.wb.y, st.wb.z, st.cosA);
+                b.lpA[sid] = make_float4(st.lightP.x, st.lightP.y, st.lightP.z, 0.f);
+                b.ray_o[2][sid] = make_float4(st.shO.x, st.shO.y, st.shO.z, st.shTmax);
+                b.ray_d[2][sid] = make_float4(st.shD.x, st.shD.y, st.shD.z, shadow_stop_t(st.shO, st.shTmax));
+                shA = true; neeA = neeCur; shCur = false; neeCur = false; closing = false;
+            }
+            prim = __float_as_int(h0.y); t = h0.x;
+            const float4 d0 = *dir0Ptr;
+            rorg = f3(cam.pos[0], cam.pos[1], cam.pos[2]); rdir = f3(d0.x, d0.y, d0.z);
+            if (prim < 0) {
+                // the pixel looks past the scene: every remaining sample is the ambient term (no draws, no rays)
+                do { st.radiance = f3(0.f, 0.f, 0.f); st.radiance += f3(1.f, 1.f, 1.f) * f3(0.1f, 0.1f, 0.1f); add_to_pixel(st.radiance); } while (--st.toStart > 0);
+                cur = false;
+            } else {
+                st.toStart--;                                            // pathtracer.cu:77-78: next sample
+                st.weight = f3(1.f, 1.f, 1.f); st.radiance = f3(0.f, 0.f, 0.f);
+                st.depth = 0; st.refractCnt = 0; bRefracted = false; cur = true;
+                go = true; fresh = true;
+            }
+        }
+        if (go) {
+            bool needSh;
+            const bool terminate = bounce(sc, prm, prim, t, rorg, rdir, st, bRefracted, neeCur, needSh);
+            shCur = needSh;
+            if (!terminate) { pathCur = true; closing = false; }
+            else {
+                pathCur = false;
+                // A path that ends with no NEE term pending has nothing to wait for.  If it is the path this step continued, it joins
+                // the pixel at once (the older closed sample was added at the top of this step, so the order of additions is kept) and
+                // the next sample can start; a sample started in this step may still have an older one sitting in slot A, so it waits
+                // as a current sample without rays and is added by the next step's "closed one step ago" branch.
+                if (needSh || fresh) closing = true;
+                else { add_to_pixel(st.radiance); cur = false; closing = false; }
+            }
+        }
+    }
+    }
     st.flags = (cur ? F_CUR : 0u) | (shCur ? F_SHADOW : 0u) | (neeCur ? F_NEEOK : 0u) | (pathCur ? F_PATH : 0u) |
                (shA ? F_SHADOWA : 0u) | (neeA ? F_NEEOKA : 0u) | (bRefracted ? F_REFR : 0u);
     return !cur && !shA && st.toStart == 0;
@@ -307,8 +359,7 @@ PT_DEV bool shade_step_t(const DevScene& sc, const DevCamera& cam, const DevPara
 PT_DEV bool shade_step(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const WfBuf& b, uint32_t sid, SState& st,
                        float2 hitP, float2 hitS, float2 hitA)
 {
-    Round1Job job;
-    return shade_step_t<false>(sc, cam, prm, b, sid, st, hitP, hitS, hitA, job);
+    return shade_step_t<true>(sc, cam, prm, b, sid, st, hitP, hitS, hitA);
 }
 
 PT_DEV void load_state(const WfBuf& b, uint32_t sid, SState& st)
@@ -355,27 +406,6 @@ PT_DEV void store_state(const WfBuf& b, uint32_t slot, const SState& st)
         b.ray_o[0][slot] = make_float4(st.pathO.x, st.pathO.y, st.pathO.z, 999999.f);
         b.ray_d[0][slot] = make_float4(st.pathD.x, st.pathD.y, st.pathD.z, -__builtin_inff());
     }
-}
-
-// A deferred round-1 bounce (shade_step_t<true>): the new sample's first bounce at the pixel's cached camera hit, then the
-// stream's state and rays go back to its slot exactly as store_state would have written them from the stream's own lane
-// (pixelColor excepted: the owner lane stores it).  flagsBase: the flag bits that do not depend on this bounce (F_CUR, slot A).
-// Returns bit 0: a path ray was queued, bit 1: a shadow ray was queued.
-PT_DEV uint32_t round1_exec(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const WfBuf& b, uint32_t sid,
-                            const Rng& rng, int toStart, uint32_t flagsBase, int prim, float t)
-{
-    SState st;
-    st.rng = rng; st.toStart = toStart; st.depth = 0; st.refractCnt = 0;
-    st.weight = f3(1.f, 1.f, 1.f); st.radiance = f3(0.f, 0.f, 0.f);
-    st.pixelColor = f3(0.f, 0.f, 0.f); st.pixLoaded = false;
-    st.cosA = 0.f; st.denom = 1.f;
-    const float4 d0 = b.dir0[sid];
-    bool bRefracted = false, neeCur = false, needSh = false;
-    const bool terminate = bounce(sc, prm, prim, t, f3(cam.pos[0], cam.pos[1], cam.pos[2]), f3(d0.x, d0.y, d0.z), st, bRefracted, neeCur, needSh);
-    const bool pathCur = !terminate, shCur = needSh;
-    st.flags = flagsBase | (shCur ? F_SHADOW : 0u) | (neeCur ? F_NEEOK : 0u) | (pathCur ? F_PATH : 0u) | (bRefracted ? F_REFR : 0u);
-    store_state(b, sid, st);
-    return (pathCur ? 1u : 0u) | (shCur ? 2u : 0u);
 }
 
 }  // namespace ptd

@@ -498,31 +498,20 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
 // ---------------------------------------------------------------------------------------
 // wf_shade: one thread per live stream, one bounce.
 // ---------------------------------------------------------------------------------------
-template <int WAVES>
+template <int WAVES, bool TWO>
 __global__ __launch_bounds__(WAVES * 256, WAVES)
 void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, int slotOut, int slotClear, int listIn)
 {
-    // Round-1 bounces of the workgroup (shade_step_t<true>: the first bounce of the next sample, for the streams whose path has
-    // just ended) are queued here and run by dense waves after a barrier.
-    constexpr int kJobWords = 10;      // sid, rng x0..x4 d, toStart | flagsBase << 16, prim, t
-    __shared__ uint32_t s_job[kJobWords][kShadeThreads];
-    __shared__ uint16_t s_owner[kShadeThreads];      // job -> owner thread
-    __shared__ uint8_t s_res[kShadeThreads];         // owner thread -> result bits of its job
-    __shared__ uint32_t s_njobs;
     const uint32_t nIn = b.cnt[slotIn].nActive;
     if (blockIdx.x == 0) for (int k = threadIdx.x; k < kWfSlotBytes / 4; k += blockDim.x) ((uint32_t*)&b.cnt[slotClear])[k] = 0;
     if ((uint32_t)blockIdx.x * blockDim.x >= nIn) return;
-    if (threadIdx.x == 0) s_njobs = 0;
-    __syncthreads();
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const bool have = idx < nIn;
-    const int lane = threadIdx.x & 63;
     bool alive = false, emit[kRayKinds] = {false, false, false};
     uint32_t sid = 0;
-    Round1Job job; job.go = false; job.prim = -1; job.t = 0.f;
-    SState st;
     if (have) {
         sid = b.active[listIn][idx];
+        SState st;
         const float2 hitP = b.hit[0][sid], hitS = b.hit[1][sid], hitA = b.hit[2][sid];      // same fetch level as the state
         load_state(b, sid, st);
         // a ray of this stream is still being traversed (time-sliced): wait one iteration
@@ -531,17 +520,9 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
         if (pendP <= -2 || pendS <= -2 || pendA <= -2) {
             alive = true; emit[0] = pendP <= -2; emit[1] = pendS <= -2; emit[2] = pendA <= -2;
         } else {
-#ifdef PT_SHADE_ROUND1_INLINE      // A/B build: every wave runs its own round-1 bounces
-            const bool done = shade_step_t<false>(sc, cam, prm, b, sid, st, hitP, hitS, hitA, job);
-#else
-            const bool done = shade_step_t<true>(sc, cam, prm, b, sid, st, hitP, hitS, hitA, job);
-#endif
+            const bool done = shade_step_t<TWO>(sc, cam, prm, b, sid, st, hitP, hitS, hitA);
             if (done) {
                 write_mean(b, prm, sid, st);
-            } else if (job.go) {
-                // the rest of this stream's step runs in round1_exec, which stores its state; the pixel sum stays with the owner
-                if (st.pixLoaded) b.pix[sid] = make_float4(st.pixelColor.x, st.pixelColor.y, st.pixelColor.z, 0.f);
-                alive = true; emit[2] = (st.flags & F_SHADOWA) != 0;
             } else {
                 const uint32_t nf = st.flags;
                 store_state(b, sid, st);
@@ -550,33 +531,6 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
             }
         }
     }
-    // queue the round-1 jobs (one LDS atomic per wave)
-    {
-        const unsigned long long m = __ballot(job.go);
-        uint32_t base = 0;
-        if (m != 0ull && lane == 0) base = atomicAdd(&s_njobs, (uint32_t)__builtin_popcountll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (job.go) {
-            const uint32_t j = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-            s_job[0][j] = sid; s_job[1][j] = st.rng.x0; s_job[2][j] = st.rng.x1; s_job[3][j] = st.rng.x2; s_job[4][j] = st.rng.x3;
-            s_job[5][j] = st.rng.x4; s_job[6][j] = st.rng.d; s_job[7][j] = (uint32_t)st.toStart | (st.flags << 16);
-            s_job[8][j] = (uint32_t)job.prim; s_job[9][j] = __float_as_uint(job.t);
-            s_owner[j] = (uint16_t)threadIdx.x;
-        }
-    }
-    __syncthreads();
-    {
-        // job j runs on thread (j + rot) mod blockDim: the busy waves of neighbouring workgroups land on different SIMDs
-        const uint32_t nj = s_njobs, rot = (blockIdx.x * 3u % (blockDim.x >> 6)) << 6;
-        const uint32_t j = (threadIdx.x + blockDim.x - rot) % blockDim.x;
-        if (j < nj) {
-            Rng rng; rng.x0 = s_job[1][j]; rng.x1 = s_job[2][j]; rng.x2 = s_job[3][j]; rng.x3 = s_job[4][j]; rng.x4 = s_job[5][j]; rng.d = s_job[6][j];
-            const uint32_t tf = s_job[7][j];
-            s_res[s_owner[j]] = (uint8_t)round1_exec(sc, cam, prm, b, s_job[0][j], rng, (int)(tf & 0xffffu), tf >> 16, (int)s_job[8][j], __uint_as_float(s_job[9][j]));
-        }
-    }
-    __syncthreads();
-    if (job.go) { const uint32_t r = s_res[threadIdx.x]; emit[0] = (r & 1u) != 0; emit[1] = (r & 2u) != 0; }
     const bool e[kLists] = {alive, emit[0], emit[1], emit[2]};
     uint32_t* const c[kLists] = {&b.cnt[slotOut].nActive, &b.cnt[slotOut].nRays[0][0], &b.cnt[slotOut].nRays[1][0], &b.cnt[slotOut].nRays[2][0]};
     uint32_t* const l[kLists] = {b.active[listIn ^ 1], b.rq[0], b.rq[1], b.rq[2]};
@@ -731,7 +685,7 @@ const float* ptk_wf_staging(void* work) { return (const float*)work; }
 // drained (it polls the live-stream count every 16..64 iterations).
 static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::DevCamera* cam, ptd::DevParams prm,
                              ptd::WfBuf b, int traceBlocks, uint32_t* h_cnt, hipStream_t stream,
-                             hipEvent_t* trace_ev, int trace_ev_pairs, int* trace_ev_used, int drainBelow, int* iters_out, unsigned long long* traceStat)
+                             hipEvent_t* trace_ev, int trace_ev_pairs, int* trace_ev_used, int drainBelow, int shadeRounds, int* iters_out, unsigned long long* traceStat)
 {
     using namespace ptd;
     hipError_t e;
@@ -762,6 +716,11 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     static const int triTrig = getenv("PTAMD_TT") ? atoi(getenv("PTAMD_TT")) : 64;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
     static const int topNodes = getenv("PTAMD_TOP") ? atoi(getenv("PTAMD_TOP")) : kTopNodes;      // quad nodes staged in LDS (0 = none)
+    // wf_shade: may a stream whose path has just ended start its next sample in the same step (a second trip through the bounce code)?
+    // It saves one iteration per sample (bounces - 1 instead of bounces) but doubles the step's dependent chain for every wave.
+    // With many streams in flight the chain is what bounds wf_shade, with few the iteration count: shadeRounds 0 / 1 forces it
+    // (pt_set_shade_rounds, PTAMD_TR), -1 switches at PTAMD_TRS live streams.  The result does not depend on it (pt_stream.h: shade_step_t).
+    static const uint32_t trStreams = getenv("PTAMD_TRS") ? (uint32_t)atoll(getenv("PTAMD_TRS")) : 4000000u;
     static const bool traceStatClk = getenv("PTAMD_TSTAT") && atoi(getenv("PTAMD_TSTAT")) == 3;      // 3: trip counters + section clocks, no histograms
     static const bool traceStatFull = getenv("PTAMD_TSTAT") && atoi(getenv("PTAMD_TSTAT")) == 1;      // 1: trip counters too (slower build); 2: timeline only
     int it = 0;
@@ -780,9 +739,11 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             else hipLaunchKernelGGL(wf_trace<0>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, 0);
             if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
             const dim3 sg((liveBound + shadeThreads - 1) / shadeThreads), sb(shadeThreads);
-            if (shadeWaves == 2) hipLaunchKernelGGL(wf_shade<2>, sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
-            else if (shadeWaves == 3) hipLaunchKernelGGL(wf_shade<3>, sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
-            else hipLaunchKernelGGL(wf_shade<4>, sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1);
+            const bool twoRounds = shadeRounds >= 0 ? (shadeRounds != 0) : (liveBound < trStreams);
+#define PT_SHADE(W, T) hipLaunchKernelGGL((wf_shade<W, T>), sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1)
+            if (twoRounds) { if (shadeWaves == 2) PT_SHADE(2, true); else if (shadeWaves == 3) PT_SHADE(3, true); else PT_SHADE(4, true); }
+            else { if (shadeWaves == 2) PT_SHADE(2, false); else if (shadeWaves == 3) PT_SHADE(3, false); else PT_SHADE(4, false); }
+#undef PT_SHADE
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(h_cnt, &b.cnt[it % 3].nActive, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
@@ -813,7 +774,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
 hipError_t ptk_wf_render(int device, const ptd::DevScene* sc, const ptd::DevCamera* cam, const ptd::DevParams* prm,
                          void* work, int traceBlocks, uint32_t* h_cnt, hipStream_t stream, hipStream_t* xstreams,
                          hipEvent_t ev_begin, hipEvent_t ev_end, hipEvent_t ev_fork, hipEvent_t* ev_join, int* iters_out,
-                         hipEvent_t* trace_ev, int trace_ev_pairs, int* trace_ev_used, int drainBelow, void* traceStat)
+                         hipEvent_t* trace_ev, int trace_ev_pairs, int* trace_ev_used, int drainBelow, int shadeRounds, void* traceStat)
 {
     using namespace ptd;
     const size_t nUnits = (size_t)prm->n_units;
@@ -840,7 +801,7 @@ hipError_t ptk_wf_render(int device, const ptd::DevScene* sc, const ptd::DevCame
         hipEvent_t* tev = trace_ev ? trace_ev + (size_t)2 * evPer * c : nullptr;
         int* used = trace_ev_used ? &trace_ev_used[c] : nullptr;
         if (cp.n_units == 0) { if (used) *used = 0; continue; }
-        auto job = [=, &rc, &iters]() { rc[(size_t)c] = run_cohort(device, sc, cam, cp, b, traceBlocks, h_cnt + 16 * c, cs, tev, evPer, used, drainBelow, &iters[(size_t)c], (unsigned long long*)traceStat); };
+        auto job = [=, &rc, &iters]() { rc[(size_t)c] = run_cohort(device, sc, cam, cp, b, traceBlocks, h_cnt + 16 * c, cs, tev, evPer, used, drainBelow, shadeRounds, &iters[(size_t)c], (unsigned long long*)traceStat); };
         if (C == 1) job(); else th.emplace_back(job);
     }
     for (auto& t : th) t.join();

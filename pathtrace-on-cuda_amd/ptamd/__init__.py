@@ -98,6 +98,7 @@ API = [
     ("pt_trace_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     ("pt_last_iterations", C.c_int, [_P]),
     ("pt_set_drain_threshold", C.c_int, [_P, C.c_int32]),
+    ("pt_set_shade_rounds", C.c_int, [_P, C.c_int32]),
 ]
 
 
@@ -294,6 +295,10 @@ class Scene:
 
     def set_drain_threshold(self, live_streams):
         _check(lib().pt_set_drain_threshold(self._h, live_streams), "pt_set_drain_threshold")
+
+    def set_shade_rounds(self, mode):
+        """1: next sample starts in the step a path ends; 0: one bounce per step; -1: by live-stream count (result-neutral)."""
+        _check(lib().pt_set_shade_rounds(self._h, mode), "pt_set_shade_rounds")
 
     def last_iterations(self):
         return lib().pt_last_iterations(self._h)

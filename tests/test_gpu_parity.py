@@ -135,6 +135,9 @@ def test_image_matches_oracle_golden(golden_dir, name, kind):
     cam = ptamd.make_camera(64, 64)
     prm = ptamd.default_params(passes=int(g["passes"]), spp_per_pass=int(g["spp"]), max_bounce=int(g["max_bounce"]))
     _check_image(sc.render(cam, prm), g["image"], name)
+    for rounds in (0, 1):      # both shading schedules of the pipeline (pt_set_shade_rounds)
+        sc.set_shade_rounds(rounds)
+        _check_image(sc.render(cam, prm), g["image"], f"{name}, shade rounds {rounds}")
 
 
 def test_config1_cornell_256_16spp_live():
@@ -329,9 +332,16 @@ def test_wavefront_pipeline_equals_state_machine_kernel():
     assert sc.last_iterations() < iters
     sc.set_drain_threshold(1 << 30)           # everything drained after the first poll
     a3 = sc.render(cam, prm)
+    sc.set_drain_threshold(0)
+    sc.set_shade_rounds(0)                    # one bounce evaluation per step: one more iteration per sample
+    a4 = sc.render(cam, prm)
+    sc.set_shade_rounds(1)
+    a5 = sc.render(cam, prm)
+    sc.set_shade_rounds(-1)
     sc.set_mode(0)
     b = sc.render(cam, prm)
     assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(a2), bits(b)) and np.array_equal(bits(a3), bits(b))
+    assert np.array_equal(bits(a4), bits(b)) and np.array_equal(bits(a5), bits(b))
     assert 5 <= iters <= 5 * (12 + 8 + 3) + 8
 
 
@@ -415,10 +425,11 @@ def test_short_paths_and_single_samples(max_bounce, rr_bounce, spp, passes):
     img_o, _ = O.Scene(nodes.tobytes(), tris, sph).render(
         O.make_camera(W, H), O.make_params(W, H, passes, spp, max_bounce=max_bounce, rr_bounce=rr_bounce), 4)
     sc = ptamd.Scene(nodes, tris, sph)
-    for mode in (1, 0):
+    for mode, rounds in ((1, 1), (1, 0), (0, -1)):
         sc.set_mode(mode)
+        sc.set_shade_rounds(rounds)
         img = sc.render(ptamd.make_camera(W, H), ptamd.default_params(passes=passes, spp_per_pass=spp, max_bounce=max_bounce, rr_bounce=rr_bounce))
-        _check_image(img, img_o, f"max_bounce {max_bounce} rr {rr_bounce} spp {spp} mode {mode}")
+        _check_image(img, img_o, f"max_bounce {max_bounce} rr {rr_bounce} spp {spp} mode {mode} shade rounds {rounds}")
 
 
 def test_stream_triad_measures_a_plausible_bandwidth():
