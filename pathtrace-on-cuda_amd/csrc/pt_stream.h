@@ -18,6 +18,7 @@ enum : uint32_t {
     F_NEEOKA = 64,    // !isnan(brdfcos) of that term
     F_CUR = 128,      // a current sample exists (started, not yet added to the pixel)
 };
+constexpr uint32_t kResumeBit = 0x80000000u;      // in a ray-queue entry: the stream's ray of that kind is a suspended traversal to resume
 constexpr int kRayKinds = 3;     // 0 path, 1 shadow of the current sample, 2 shadow of the older closed sample
 
 // Shadow rays only decide whether the closest hit is the sampled light point (GetLightColor, CudaUtil.cuh:150-166: visible iff

@@ -76,7 +76,7 @@ constexpr int kTopStride = 5;         // uint4 per staged node
 constexpr int kShadeThreads = 1024;      // largest wf_shade workgroup (the default runs 256-thread workgroups, 3 per CU at 146 VGPRs, no spills)
 constexpr int kLists = 1 + kRayKinds;
 template <int N>
-PT_DEV void block_append(const bool (&e)[N], uint32_t id, uint32_t* const (&c)[N], uint32_t* const (&l)[N])
+PT_DEV void block_append(const bool (&e)[N], const uint32_t (&id)[N], uint32_t* const (&c)[N], uint32_t* const (&l)[N])
 {
     constexpr int W = kShadeThreads / 64;
     __shared__ uint32_t s_cnt[N][W];
@@ -98,7 +98,7 @@ PT_DEV void block_append(const bool (&e)[N], uint32_t id, uint32_t* const (&c)[N
     for (int k = 0; k < N; k++) {
         uint32_t pos = s_base[k];
         for (int w = 0; w < wave; w++) pos += s_cnt[k][w];
-        if (e[k]) l[k][pos + (uint32_t)__builtin_popcountll(m[k] & below)] = id;
+        if (e[k]) l[k][pos + (uint32_t)__builtin_popcountll(m[k] & below)] = id[k];
     }
 }
 
@@ -128,7 +128,8 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
     const bool e[kLists] = {live, live, false, false};
     uint32_t* const c[kLists] = {&b.cnt[0].nActive, &b.cnt[0].nRays[0][0], &b.cnt[0].nRays[1][0], &b.cnt[0].nRays[2][0]};
     uint32_t* const l[kLists] = {b.active[0], b.rq[0], b.rq[1], b.rq[2]};
-    block_append<kLists>(e, sid, c, l);
+    const uint32_t ids[kLists] = {sid, sid, sid, sid};
+    block_append<kLists>(e, ids, c, l);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -258,7 +259,8 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
 #endif
                         kind = q < nPath ? 0 : (q < nKind1 ? 1 : 2);
                         // the per-kind arrays lie back to back at a stride of n16 elements (WfBuf): one base pointer each
-                        sid = kind == 0 ? b.rq[0][q] : (kind == 1 ? b.rq[1][q - nPath] : b.rq[2][q - nKind1]);
+                        const uint32_t qid = kind == 0 ? b.rq[0][q] : (kind == 1 ? b.rq[1][q - nPath] : b.rq[2][q - nKind1]);
+                        sid = qid & ~kResumeBit;
                         const float4 o = (kind == 0 ? b.ray_o[0] : (kind == 1 ? b.ray_o[1] : b.ray_o[2]))[sid];
                         const float4 d = (kind == 0 ? b.ray_d[0] : (kind == 1 ? b.ray_d[1] : b.ray_d[2]))[sid];
                         org = f3(o.x, o.y, o.z); dir = f3(d.x, d.y, d.z);
@@ -276,10 +278,11 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                         }
                         stopBelow = kind != 0 ? d.w : -__builtin_inff();      // shadow rays: any hit below this t ends the traversal (pt_stream.h: shadow_stop_t)
                         steps = 0;
-                        const float2 prev = (kind == 0 ? b.hit[0] : (kind == 1 ? b.hit[1] : b.hit[2]))[sid];
-                        const int pp = __float_as_int(prev.y);
-                        if (pp <= -2) {
-                            // resume a suspended traversal
+                        if (qid & kResumeBit) {
+                            // resume a suspended traversal (wf_shade flags the queue entry: the hit slot then holds the record number;
+                            // a fresh ray's hit slot is not read at all — 8 scattered bytes per ray that nothing else would fetch)
+                            const float2 prev = (kind == 0 ? b.hit[0] : (kind == 1 ? b.hit[1] : b.hit[2]))[sid];
+                            const int pp = __float_as_int(prev.y);
                             const int* rec = suspIn + (size_t)(-2 - pp) * kSuspInts;
                             cur = rec[0]; sp = rec[1]; bestT = __int_as_float(rec[2]); bestPrim = rec[3];
                             for (int k = 0; k < sp; k++) {
@@ -508,7 +511,7 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const bool have = idx < nIn;
     bool alive = false, emit[kRayKinds] = {false, false, false};
-    uint32_t sid = 0;
+    uint32_t sid = 0, resume = 0;      // resume: the queued rays are suspended traversals (wf_trace then reads their records)
     if (have) {
         sid = b.active[listIn][idx];
         SState st;
@@ -518,7 +521,7 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
         const int pendP = (st.flags & F_PATH) ? __float_as_int(hitP.y) : -1, pendS = (st.flags & F_SHADOW) ? __float_as_int(hitS.y) : -1;
         const int pendA = (st.flags & F_SHADOWA) ? __float_as_int(hitA.y) : -1;
         if (pendP <= -2 || pendS <= -2 || pendA <= -2) {
-            alive = true; emit[0] = pendP <= -2; emit[1] = pendS <= -2; emit[2] = pendA <= -2;
+            alive = true; emit[0] = pendP <= -2; emit[1] = pendS <= -2; emit[2] = pendA <= -2; resume = kResumeBit;
         } else {
             const bool done = shade_step_t<TWO>(sc, cam, prm, b, sid, st, hitP, hitS, hitA);
             if (done) {
@@ -534,7 +537,8 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
     const bool e[kLists] = {alive, emit[0], emit[1], emit[2]};
     uint32_t* const c[kLists] = {&b.cnt[slotOut].nActive, &b.cnt[slotOut].nRays[0][0], &b.cnt[slotOut].nRays[1][0], &b.cnt[slotOut].nRays[2][0]};
     uint32_t* const l[kLists] = {b.active[listIn ^ 1], b.rq[0], b.rq[1], b.rq[2]};
-    block_append<kLists>(e, sid, c, l);
+    const uint32_t ids[kLists] = {sid, sid | resume, sid | resume, sid | resume};
+    block_append<kLists>(e, ids, c, l);
 }
 
 // ---------------------------------------------------------------------------------------
