@@ -16,7 +16,7 @@
 //  quad node (64 B, 16 dwords) — the 4-wide collapse of the same tree, walked by wf_trace.  Child boxes are
 //      quantised to 8 bits per coordinate against the node's origin and per-axis power-of-two scale,
 //      rounded outward (host/accel_build.cpp):
-//        d0..2  origin.xyz (float)      d3  ex | ey<<8 | ez<<16 (int8 exponents: scale = 2^e)
+//        d0..2  origin.xyz (float)      d3, d14, d15  per-axis scale 2^ex, 2^ey, 2^ez (floats)
 //        d4..7  child refs (same encoding as above; ~0 = no child, its box is inverted)
 //        d8..10 lo.x lo.y lo.z          d11..13 hi.x hi.y hi.z   (byte k of each dword = child k)
 //      child box = origin + scale * q

@@ -348,24 +348,21 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 // of a coordinate share a dword), and the far side is cut at the closest hit.  The boxes only
                 // steer the search — acceptance is Triangle::hit + the reference's leaf box — so all that
                 // matters is that no box containing a point the ray reaches is ever rejected.
-                uint4 n0, n1, n2; uint2 n3;
+                uint4 n0, n1, n2, n3;
 #if TRACE_TOP_NODES > 0
                 if (cur < topN) {
                     // explicit LDS reads: left to itself the compiler merges the two address spaces into flat_load instructions,
                     // which cost the whole kernel 18 % (every node fetch then waits on both counters and the ray origin spills)
                     const uint32_t la = (uint32_t)(uintptr_t)(lds_top + cur * kTopStride);
-                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b64 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
                                  : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3) : "v"(la) : "memory");
                 } else
 #endif
                 {
                     const uint4* np = sc.quad + 4 * (size_t)cur;
-                    n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = *(const uint2*)(np + 3);
+                    n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3];
                 }
-                const int eb = (int)n0.w;
-                const float Ax = __builtin_ldexpf(inv.x, (int)(signed char)(eb & 0xff));
-                const float Ay = __builtin_ldexpf(inv.y, (int)(signed char)((eb >> 8) & 0xff));
-                const float Az = __builtin_ldexpf(inv.z, (int)(signed char)((eb >> 16) & 0xff));
+                const float Ax = inv.x * __uint_as_float(n0.w), Ay = inv.y * __uint_as_float(n3.z), Az = inv.z * __uint_as_float(n3.w);      // scales are powers of two
                 const float Bx = (__uint_as_float(n0.x) - org.x) * inv.x;
                 const float By = (__uint_as_float(n0.y) - org.y) * inv.y;
                 const float Bz = (__uint_as_float(n0.z) - org.z) * inv.z;

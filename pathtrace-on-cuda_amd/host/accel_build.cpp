@@ -311,11 +311,11 @@ void pt_build_accel(const PtBVHNode* rnodes, int n_rnodes, const PtTriangle* tri
             }
             Q4& q = quad[(size_t)me];
             memcpy(&q.d[0], org, 12);
-            q.d[3] = ((uint32_t)(uint8_t)(int8_t)e[0]) | ((uint32_t)(uint8_t)(int8_t)e[1] << 8) | ((uint32_t)(uint8_t)(int8_t)e[2] << 16);
+            { const float sx = std::ldexp(1.f, e[0]), sy = std::ldexp(1.f, e[1]), sz = std::ldexp(1.f, e[2]);      // the scales as floats: one multiply per axis in the kernel
+              memcpy(&q.d[3], &sx, 4); memcpy(&q.d[14], &sy, 4); memcpy(&q.d[15], &sz, 4); }
             for (int k = 0; k < 4; k++) q.d[4 + k] = refs[k];
             q.d[8] = qlo[0]; q.d[9] = qlo[1]; q.d[10] = qlo[2];
             q.d[11] = qhi[0]; q.d[12] = qhi[1]; q.d[13] = qhi[2];
-            q.d[14] = 0; q.d[15] = 0;
             return me;
         }
     };
@@ -334,7 +334,8 @@ void pt_build_accel(const PtBVHNode* rnodes, int n_rnodes, const PtTriangle* tri
             for (;;) { const float sc = std::ldexp(1.f, ex); int q1 = (int)std::ceil((mx - mn) / sc); while (q1 <= 255 && mn + sc * (float)q1 < mx) q1++; if (q1 <= 255) { qh[a] = (uint32_t)q1; e[a] = ex; break; } ex++; }
         }
         memcpy(&q.d[0], org, 12);
-        q.d[3] = ((uint32_t)(uint8_t)(int8_t)e[0]) | ((uint32_t)(uint8_t)(int8_t)e[1] << 8) | ((uint32_t)(uint8_t)(int8_t)e[2] << 16);
+        { const float sx = std::ldexp(1.f, e[0]), sy = std::ldexp(1.f, e[1]), sz = std::ldexp(1.f, e[2]);
+          memcpy(&q.d[3], &sx, 4); memcpy(&q.d[14], &sy, 4); memcpy(&q.d[15], &sz, 4); }
         q.d[4] = (uint32_t)~((b.nodes[0].first << 3) | b.nodes[0].count);
         q.d[5] = q.d[6] = q.d[7] = (uint32_t)~0;
         for (int a = 0; a < 3; a++) { q.d[8 + a] = 0u | (255u << 8) | (255u << 16) | (255u << 24); q.d[11 + a] = qh[a]; }

@@ -43,8 +43,7 @@ static void walk(int32_t ref, int depth, float* mn, float* mx)
         float cmn[3], cmx[3];
         walk(cr, depth + 1, cmn, cmx);
         for (int a = 0; a < 3; a++) {
-            const int e = (int)(signed char)((d[3] >> (8 * a)) & 0xff);
-            const float sc = std::ldexp(1.f, e);
+            float sc; memcpy(&sc, &d[a == 0 ? 3 : 13 + a], 4);      // per-axis scale 2^e, stored as a float (d3, d14, d15)
             const float lo = org[a] + sc * (float)((d[8 + a] >> (8 * k)) & 0xff), hi = org[a] + sc * (float)((d[11 + a] >> (8 * k)) & 0xff);
             if (!(lo <= cmn[a] && hi >= cmx[a])) { if (bad++ < 10) printf("BAD box node %d child %d axis %d: [%g,%g] vs [%g,%g]\n", ref, k, a, lo, hi, cmn[a], cmx[a]); }
             mn[a] = std::fmin(mn[a], cmn[a]); mx[a] = std::fmax(mx[a], cmx[a]);
