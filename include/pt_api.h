@@ -286,10 +286,11 @@ PT_API int  pt_last_iterations(PtScene* s);
  * most `live_streams` are still alive (0 = never, the default: on MI355X the drain launch measured
  * slower than the latency-bound iterations it replaces).  Result-neutral. */
 PT_API int  pt_set_drain_threshold(PtScene* s, int32_t live_streams);
-/* Mode 1, shading schedule: 1 (default) = a stream whose path ends starts its next sample in the same step (bounces - 1 steps per
- * sample, two bounce evaluations per step), 0 = one bounce evaluation per step (bounces steps per sample, a shorter step: +10 % on
- * the Cornell room, -6 % for one rank of an 8-way split of the bunny frame), -1 = 0 while more than PTAMD_TRS (4 M) streams are
- * alive, 1 below.  Result-neutral: a stream goes through the same operations in the same order either way
+/* Mode 1, shading schedule: 1 = a stream whose path ends starts its next sample in the same step (bounces - 1 steps per sample,
+ * two bounce evaluations per step), 0 = one bounce evaluation per step (bounces steps per sample, a shorter step), -1 = 0 while
+ * more than PTAMD_TRS (4 M) streams are alive, 1 below.  Default: -1 for scenes whose surface table fits in L2 (<= 2 MB: +10 % on
+ * the Cornell room), 1 otherwise (with the bunny one bounce per step is neutral on a full frame and costs 6 % for one rank of an
+ * 8-way split).  Result-neutral: a stream goes through the same operations in the same order either way
  * (pathtrace-on-cuda_amd/csrc/pt_stream.h: shade_step_t). */
 PT_API int  pt_set_shade_rounds(PtScene* s, int32_t mode);
 /* Run the counting build of the kernel on the next pt_render_tiles calls (slower; mode 0). */
