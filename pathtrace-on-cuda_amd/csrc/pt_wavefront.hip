@@ -196,7 +196,6 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
     bool exhausted = false;                // wave-uniform
     bool hasRay = false;
     // per-ray registers
-    uint32_t sid = 0;
     // inv: the reference's Normalize(inv(dir)) (CudaUtil.cuh:70) — what its leaf-box test uses, and a perfectly good
     // inverse direction for the tree walk, which then measures t in units of 1/|inv(dir)|; cscale converts the
     // closest hit into those units.  Degenerate rays (a zero direction component): 1/dir clamped to +-1e30, true units.
@@ -205,7 +204,10 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
     int bestPrim = -1, cur = kDone, sp = 0, steps = 0;
     int pend = 0;        // a leaf this ray has reached but not yet tested (0 = none): see "postponed leaves" below
     bool degenerate = false;
-    int kind = 0;        // 0 path, 1/2 shadow (pt_stream.h)
+    // The per-kind arrays of WfBuf lie back to back (hit[k] = hit[0] + k * n16, rq[k] likewise, ray_o[k] = ray_o[0] + 2 k n16, ray_d[k] = ray_o[k] + n16):
+    // a ray is known by hs = kind * n16 + stream id, its hit slot is hit[0][hs], and no pointer is ever selected by kind.
+    const uint32_t n16 = (uint32_t)(b.hit[1] - b.hit[0]);
+    uint32_t hs = 0;
 
     for (;;) {
         // ---- hand new rays to idle lanes (ballot + mbcnt compaction) ----
@@ -257,12 +259,21 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
 #else
                         const uint32_t q = ((j / kShardBlock) * kWfShards + (uint32_t)shard) * kShardBlock + (j % kShardBlock);
 #endif
-                        kind = q < nPath ? 0 : (q < nKind1 ? 1 : 2);
-                        // the per-kind arrays lie back to back at a stride of n16 elements (WfBuf): one base pointer each
+#ifdef PT_KIND_POINTERS      // A/B build: array pointers selected by the ray's kind
+                        const int kind = q < nPath ? 0 : (q < nKind1 ? 1 : 2);
                         const uint32_t qid = kind == 0 ? b.rq[0][q] : (kind == 1 ? b.rq[1][q - nPath] : b.rq[2][q - nKind1]);
-                        sid = qid & ~kResumeBit;
+                        const uint32_t sid = qid & ~kResumeBit;
+                        hs = (uint32_t)kind * n16 + sid;
                         const float4 o = (kind == 0 ? b.ray_o[0] : (kind == 1 ? b.ray_o[1] : b.ray_o[2]))[sid];
                         const float4 d = (kind == 0 ? b.ray_d[0] : (kind == 1 ? b.ray_d[1] : b.ray_d[2]))[sid];
+#else
+                        const bool k0 = q < nPath, k1 = q < nKind1;                       // kind 0 / kind 0 or 1
+                        const uint32_t qid = b.rq[0][q + (k0 ? 0u : (k1 ? n16 - nPath : 2u * n16 - nKind1))];
+                        const uint32_t kn = k0 ? 0u : (k1 ? n16 : 2u * n16);              // kind * n16
+                        hs = kn + (qid & ~kResumeBit);
+                        const float4 o = b.ray_o[0][hs + kn], d = b.ray_d[0][hs + kn];
+                        const int kind = k0 ? 0 : 1;      // all that is still asked of it: path ray or not
+#endif
                         org = f3(o.x, o.y, o.z); dir = f3(d.x, d.y, d.z);
                         inv = f3(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);                     // inv(), CudaUtil.cuh:60-63
                         const float L = __builtin_sqrtf(inv.x * inv.x + inv.y * inv.y + inv.z * inv.z);
@@ -281,7 +292,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                         if (qid & kResumeBit) {
                             // resume a suspended traversal (wf_shade flags the queue entry: the hit slot then holds the record number;
                             // a fresh ray's hit slot is not read at all — 8 scattered bytes per ray that nothing else would fetch)
-                            const float2 prev = (kind == 0 ? b.hit[0] : (kind == 1 ? b.hit[1] : b.hit[2]))[sid];
+                            const float2 prev = b.hit[0][hs];
                             const int pp = __float_as_int(prev.y);
                             const int* rec = suspIn + (size_t)(-2 - pp) * kSuspInts;
                             cur = rec[0]; sp = rec[1]; bestT = __int_as_float(rec[2]); bestPrim = rec[3];
@@ -314,7 +325,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                         if (pend != 0) { if (sp < kWfLdsStack) stack[sp * 64] = pend; else ovf[(sp - kWfLdsStack) * ovfStride] = pend; sp++; pend = 0; }
                         r[0] = cur; r[1] = sp; r[2] = __float_as_int(bestT); r[3] = bestPrim;
                         for (int k = 0; k < sp; k++) r[4 + k] = (k < kWfLdsStack) ? stack[k * 64] : ovf[(k - kWfLdsStack) * ovfStride];
-                        (kind == 0 ? b.hit[0] : (kind == 1 ? b.hit[1] : b.hit[2]))[sid] = make_float2(bestT, __int_as_float(-2 - (int)rec));
+                        b.hit[0][hs] = make_float2(bestT, __int_as_float(-2 - (int)rec));
                         hasRay = false;
                         cur = kDone;
                     } else {
@@ -465,7 +476,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     float root;
                     if (sphere_root(f3(c.x, c.y, c.z), c.w, org, dir, bestT, root)) { bestT = root; bestPrim = sc.n_tris + s; }
                 }
-                (kind == 0 ? b.hit[0] : (kind == 1 ? b.hit[1] : b.hit[2]))[sid] = make_float2(bestT, __int_as_float(bestPrim));
+                b.hit[0][hs] = make_float2(bestT, __int_as_float(bestPrim));
                 hasRay = false;
                 if (STAT) stRays++;
                 if (HIST) atomicAdd(&stat[8 + 3 * 2700 + 32 + 2700 + (steps >= 252 ? 63 : steps >> 2)], 1ull);      // node steps of this ray (this launch), bins of 4
