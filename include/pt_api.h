@@ -239,6 +239,10 @@ PT_API int  pt_dbg_raycast(PtScene* s, const float* rays8, int32_t n, float* out
 PT_API int  pt_dbg_bxdf(int32_t device, int32_t lobe, const float* in28, int32_t n, float* out12);
 PT_API int  pt_dbg_rng(int32_t device, uint64_t seed, int32_t n, uint32_t* raw_out, float* uniform_out);
 PT_API int  pt_dbg_math(int32_t device, const float* in, int32_t n, float* out8);
+/* The per-ray set-up of the traversal kernel (csrc/pt_trace.h: ray_setup) on n directions (3 floats each): out5 = the reference's
+ * Normalize(inv(dir)) (include/CudaUtil.cuh:60-63, :70) x, y, z | the kernel's cull scale | 1.0 for a degenerate direction; the
+ * test compares it with IEEE arithmetic bit for bit. */
+PT_API int  pt_dbg_ray_setup(int32_t device, const float* dir3, int32_t n, float* out5);
 /* StartRender's prologue + GetPixelDirection (srcs/pathtracer.cu:33-40,70-74) for n rows (px, py, pass) of int32:
  * out8 = u1 u2 | dir.xyz (after the Ray constructor's second normalisation) | the RNG's next uniform draw | 0 0. */
 PT_API int  pt_dbg_pixel_dir(int32_t device, const PtCamera* cam, const int32_t* pxpypass, int32_t n, float* out8);

@@ -26,6 +26,7 @@ hipError_t ptk_dbg_raycast(const ptd::DevScene*, const float*, int, float*, int*
 hipError_t ptk_dbg_bxdf(int, const float*, int, float*, hipStream_t);
 hipError_t ptk_dbg_rng(unsigned long long, int, uint32_t*, float*, hipStream_t);
 hipError_t ptk_dbg_math(const float*, int, float*, hipStream_t);
+hipError_t ptk_dbg_ray_setup(const float*, int, float*, hipStream_t);
 hipError_t ptk_dbg_pixel_dir(const ptd::DevCamera*, const int*, int, float*, hipStream_t);
 hipError_t ptk_dbg_nee(const ptd::DevScene*, const float*, int, float*, hipStream_t);
 size_t ptk_wf_work_bytes(size_t nUnits, int traceBlocks);
@@ -611,6 +612,12 @@ int pt_dbg_nee(PtScene* s, const float* in5, int32_t n, float* out12)
                         [&](void* i, void* o, void*) { return ptk_dbg_nee(&s->dev, (const float*)i, n, (float*)o, nullptr); });
 }
 
+int pt_dbg_ray_setup(int32_t device, const float* dir3, int32_t n, float* out5)
+{
+    if (!dir3 || !out5 || n < 0) { pt_set_error("pt_dbg_ray_setup: bad argument"); return PT_ERR_INVALID; }
+    return with_buffers(device, dir3, (size_t)n * 12, out5, (size_t)n * 20, nullptr, 0,
+                        [&](void* i, void* o, void*) { return ptk_dbg_ray_setup((const float*)i, n, (float*)o, nullptr); });
+}
 int pt_dbg_math(int32_t device, const float* in, int32_t n, float* out8)
 {
     if (!in || !out8 || n < 0) { pt_set_error("pt_dbg_math: bad argument"); return PT_ERR_INVALID; }

@@ -75,6 +75,26 @@ PT_DEV bool box_test_robust(float bminx, float bminy, float bminz, float bmaxx, 
     return ok & (lo * (1.f - kPad) <= hi * (1.f + kPad) + 1e-30f) & (lo <= cullB);
 }
 
+// Per-ray set-up of the quad-tree walk (wf_trace's refill; parity hook pt_dbg_ray_setup): inv = the reference's Normalize(inv(dir))
+// (CudaUtil.cuh:60-63, :70) — what its leaf-box test uses, and a perfectly good inverse direction for the tree walk, which then
+// measures t in units of 1/|inv(dir)| —, cscale = what converts the closest hit into those units, degenerate = a direction with a
+// zero component (L = inf: 1/dir clamped to +-1e30, true units, no leaf-box test; see box_test_robust).
+PT_DEV void ray_setup(const f3& dir, f3& inv, float& cscale, bool& degenerate)
+{
+    inv = f3(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);                     // inv(), CudaUtil.cuh:60-63
+    const float L = __builtin_sqrtf(inv.x * inv.x + inv.y * inv.y + inv.z * inv.z);
+    degenerate = !(L < __builtin_inff());
+    if (!degenerate) {
+        inv = inv / L;                                                   // Normalize(inv(dir)), :70
+        cscale = __builtin_amdgcn_rcpf(L) * 1.0000019f;                  // 1/L, rounded up a little: the cull must not bite early
+    } else {
+        inv.x = (__builtin_fabsf(inv.x) <= 1e30f) ? inv.x : __builtin_copysignf(1e30f, dir.x);
+        inv.y = (__builtin_fabsf(inv.y) <= 1e30f) ? inv.y : __builtin_copysignf(1e30f, dir.y);
+        inv.z = (__builtin_fabsf(inv.z) <= 1e30f) ? inv.z : __builtin_copysignf(1e30f, dir.z);
+        cscale = 1.0000019f;
+    }
+}
+
 // Moeller-Trumbore with the reference's back-face cull and test order,
 // Triangle::hit, include/CudaPrimitive.cuh:89-118.  `q` indexes the tree-ordered records; the
 // record carries the triangle's index in the reference's order (tie rule: among equal t the

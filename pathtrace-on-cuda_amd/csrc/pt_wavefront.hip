@@ -275,18 +275,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                         const int kind = k0 ? 0 : 1;      // all that is still asked of it: path ray or not
 #endif
                         org = f3(o.x, o.y, o.z); dir = f3(d.x, d.y, d.z);
-                        inv = f3(1.f / dir.x, 1.f / dir.y, 1.f / dir.z);                     // inv(), CudaUtil.cuh:60-63
-                        const float L = __builtin_sqrtf(inv.x * inv.x + inv.y * inv.y + inv.z * inv.z);
-                        degenerate = !(L < __builtin_inff());
-                        if (!degenerate) {
-                            inv = inv / L;                                                   // Normalize(inv(dir)), :70
-                            cscale = __builtin_amdgcn_rcpf(L) * 1.0000019f;                  // 1/L, rounded up a little: the cull must not bite early
-                        } else {
-                            inv.x = (__builtin_fabsf(inv.x) <= 1e30f) ? inv.x : __builtin_copysignf(1e30f, dir.x);
-                            inv.y = (__builtin_fabsf(inv.y) <= 1e30f) ? inv.y : __builtin_copysignf(1e30f, dir.y);
-                            inv.z = (__builtin_fabsf(inv.z) <= 1e30f) ? inv.z : __builtin_copysignf(1e30f, dir.z);
-                            cscale = 1.0000019f;
-                        }
+                        ray_setup(dir, inv, cscale, degenerate);      // pt_trace.h
                         stopBelow = kind != 0 ? d.w : -__builtin_inff();      // shadow rays: any hit below this t ends the traversal (pt_stream.h: shadow_stop_t)
                         steps = 0;
                         if (qid & kResumeBit) {
@@ -588,6 +577,14 @@ void wf_drain(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
 // functions the render kernels call (pt_shade.h), run on rows of inputs so that tests can compare them with the oracle
 // one function at a time.
 // ---------------------------------------------------------------------------------------
+__global__ void dbg_ray_setup(const float* __restrict__ dir3, int n, float* __restrict__ out5)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    f3 inv; float cscale; bool deg;
+    ray_setup(f3(dir3[3 * i], dir3[3 * i + 1], dir3[3 * i + 2]), inv, cscale, deg);
+    out5[5 * i] = inv.x; out5[5 * i + 1] = inv.y; out5[5 * i + 2] = inv.z; out5[5 * i + 3] = cscale; out5[5 * i + 4] = deg ? 1.f : 0.f;
+}
 __global__ void dbg_pixel_dir(DevCamera cam, const int* __restrict__ pxpypass, int n, float* __restrict__ out8)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -829,6 +826,12 @@ hipError_t ptk_wf_render(int device, const ptd::DevScene* sc, const ptd::DevCame
     return hipSuccess;
 }
 
+hipError_t ptk_dbg_ray_setup(const float* dir3, int n, float* out5, hipStream_t stream)
+{
+    const int nb = (n + 255) / 256;
+    if (nb > 0) hipLaunchKernelGGL(ptd::dbg_ray_setup, dim3(nb), dim3(256), 0, stream, dir3, n, out5);
+    return hipGetLastError();
+}
 hipError_t ptk_dbg_pixel_dir(const ptd::DevCamera* cam, const int* pxpypass, int n, float* out8, hipStream_t stream)
 {
     const int nb = (n + 255) / 256;

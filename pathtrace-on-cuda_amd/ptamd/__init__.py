@@ -86,6 +86,7 @@ API = [
     ("pt_dbg_bxdf", C.c_int, [C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     ("pt_dbg_rng", C.c_int, [C.c_int32, C.c_uint64, C.c_int32, _P, _P]),
     ("pt_dbg_math", C.c_int, [C.c_int32, _P, C.c_int32, _P]),
+    ("pt_dbg_ray_setup", C.c_int, [C.c_int32, _P, C.c_int32, _P]),
     ("pt_dbg_pixel_dir", C.c_int, [C.c_int32, C.POINTER(PtCamera), _P, C.c_int32, _P]),
     ("pt_dbg_nee", C.c_int, [_P, _P, C.c_int32, _P]),
     ("pt_dbg_triad", C.c_int, [C.c_int32, C.c_int64, C.c_int32, _P]),
@@ -445,6 +446,14 @@ def dbg_pixel_dir(cam, pxpypass, device=0):
     a = np.ascontiguousarray(pxpypass, np.int32).reshape(-1, 3)
     out = np.zeros((a.shape[0], 8), np.float32)
     _check(lib().pt_dbg_pixel_dir(device, C.byref(cam), _ptr(a), a.shape[0], _ptr(out)), "pt_dbg_pixel_dir")
+    return out
+
+
+def dbg_ray_setup(dirs, device=0):
+    """wf_trace's per-ray set-up on (n, 3) directions -> (n, 5): Normalize(inv(dir)) xyz, cull scale, degenerate flag."""
+    d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+    out = np.zeros((d.shape[0], 5), np.float32)
+    _check(lib().pt_dbg_ray_setup(device, _ptr(d), d.shape[0], _ptr(out)), "pt_dbg_ray_setup")
     return out
 
 

@@ -65,6 +65,33 @@ def test_device_arithmetic_is_ieee_and_correctly_rounded():
         assert bad <= 1, f"column {col}: {bad} results not correctly rounded"
 
 
+def test_ray_setup_matches_ieee_arithmetic():
+    """wf_trace's per-ray set-up (pt_trace.h: ray_setup — the reference's Normalize(inv(dir)), its degenerate case and the clamp)
+    bit for bit against IEEE arithmetic (numpy float32) on a million directions: unit vectors, components down to 1e-30, exact
+    powers of two, zeros (degenerate), very large and very small magnitudes."""
+    rs = np.random.RandomState(5)
+    n = 1 << 20
+    d = rs.standard_normal((n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[: n // 8] *= 10.0 ** rs.uniform(-30, 0, (n // 8, 3))                 # tiny components: huge inverses
+    d[n // 8: n // 4] *= 2.0 ** rs.randint(-60, 60, (n // 8, 3))          # beyond +-2^40
+    d[n // 4: n // 4 + 4096, rs.randint(0, 3)] = 0.0                        # degenerate
+    d[n // 4 + 4096: n // 4 + 8192] = 2.0 ** rs.randint(-3, 3, (4096, 3))  # exact powers of two
+    d = d.astype(np.float32)
+    out = ptamd.dbg_ray_setup(d)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        inv = np.float32(1) / d
+        L = np.sqrt((inv[:, 0] * inv[:, 0] + inv[:, 1] * inv[:, 1]) + inv[:, 2] * inv[:, 2])
+        deg = ~(L < np.float32(np.inf))
+        ref = inv / L[:, None]
+    assert np.array_equal(out[:, 4] != 0, deg)
+    ok = ~deg
+    assert ok.sum() > n // 2
+    assert np.array_equal(bits(out[ok, :3]), bits(ref[ok])), "normalised inverse direction differs from IEEE division"
+    clamp = np.where(np.abs(inv[deg]) <= np.float32(1e30), inv[deg], np.copysign(np.float32(1e30), d[deg]))
+    assert np.array_equal(bits(out[deg, :3]), bits(clamp.astype(np.float32)))
+
+
 def _bxdf_inputs(n, rs, lobe):
     nrm = rs.standard_normal((n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
     t = np.cross(nrm, rs.standard_normal((n, 3))); t /= np.linalg.norm(t, axis=1, keepdims=True)
