@@ -129,65 +129,18 @@ PT_DEV void tri_test(const DevScene& sc, int q, const f3& org, const f3& dir, co
     bestT = t; bestPrim = prim;
 }
 
-// Two triangles of one leaf in one go (wf_trace).  The arithmetic of Triangle::hit up to det, t's numerator, u and v
-// is done on both triangles at once with 2-wide vectors, which the compiler turns into packed
-// v_pk_mul_f32 / v_pk_add_f32: one instruction serves both triangles, and each lane of a packed operation is an
-// ordinary IEEE operation (no contraction: -ffp-contract=off), so every value has the bits tri_test computes.
-// The decisions and the leaf-box check then run per triangle, in index order, exactly as tri_test does.
-// `two` = false: the second triangle is a copy of the first and is skipped.
-PT_DEV void tri_test_pair(const DevScene& sc, int q, bool two, const f3& org, const f3& dir, const f3& invD, bool degenerate,
-                          float& bestT, int& bestPrim)
-{
-    typedef float f2v __attribute__((ext_vector_type(2)));
-    const int q1 = two ? q + 1 : q;
-    const float4 a0 = sc.tri[3 * q], b0 = sc.tri[3 * q + 1], c0 = sc.tri[3 * q + 2];
-    const float4 a1 = sc.tri[3 * q1], b1 = sc.tri[3 * q1 + 1], c1 = sc.tri[3 * q1 + 2];
-    const f2v ox = {org.x, org.x}, oy = {org.y, org.y}, oz = {org.z, org.z};
-    const f2v dx = {dir.x, dir.x}, dy = {dir.y, dir.y}, dz = {dir.z, dir.z};
-    const f2v E1x = {b0.x, b1.x}, E1y = {b0.y, b1.y}, E1z = {b0.z, b1.z};
-    const f2v E2x = {c0.x, c1.x}, E2y = {c0.y, c1.y}, E2z = {c0.z, c1.z};
-    // T = org - V0
-    const f2v Tx = ox - (f2v){a0.x, a1.x}, Ty = oy - (f2v){a0.y, a1.y}, Tz = oz - (f2v){a0.z, a1.z};
-    // P = cross(dir, E2), Q = cross(T, E1), operation for operation as cross() in pt_math.h:
-    // (a.y*b.z - a.z*b.y, -(a.x*b.z - a.z*b.x), a.x*b.y - a.y*b.x)
-    const f2v Px = dy * E2z - dz * E2y, Py = -(dx * E2z - dz * E2x), Pz = dx * E2y - dy * E2x;
-    const f2v Qx = Ty * E1z - Tz * E1y, Qy = -(Tx * E1z - Tz * E1x), Qz = Tx * E1y - Ty * E1x;
-    const f2v det = Px * E1x + Py * E1y + Pz * E1z;          // dot(P, E1)
-    const f2v tnum = Qx * E2x + Qy * E2y + Qz * E2z;         // dot(Q, E2)
-    const f2v uu = Px * Tx + Py * Ty + Pz * Tz;              // dot(P, T)
-    const f2v vv = Qx * dx + Qy * dy + Qz * dz;              // dot(Q, dir)
-#pragma nounroll
-    for (int j = 0; j < 2; j++) {
-        if (j == 1 && !two) break;
-        const float d = j ? det.y : det.x;
-        if (d < kEps) continue;
-        const float invDet = 1.f / d;
-        const float t = (j ? tnum.y : tnum.x) * invDet;
-        if (t < 0.f || t > bestT) continue;
-        const float u = j ? uu.y : uu.x;
-        if (u < 0.f || u > d) continue;
-        const float v = j ? vv.y : vv.x;
-        if (v < 0.f || (v + u) > d) continue;
-        const int prim = __float_as_int(j ? a1.w : a0.w);
-        if (!(t < bestT || prim > bestPrim)) continue;
-        if (!degenerate) {
-            const int leaf = __float_as_int(j ? b1.w : b0.w);
-            const float4 l0 = sc.leafbox[2 * leaf], l1 = sc.leafbox[2 * leaf + 1];
-            float tn;
-            if (!box_test(l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, org, invD, __builtin_inff(), tn)) continue;
-        }
-        bestT = t; bestPrim = prim;
-    }
-}
-
-// The same two-triangle test on a pair record (pt_device.h: tripair) — the operand pairs come interleaved from memory,
-// so no register moves are needed to form them —, with the per-triangle decisions as straight-line selects:
+// Two triangles of one leaf in one go (wf_trace).  The arithmetic of Triangle::hit up to det, t's numerator, u and v is done on both
+// triangles at once with 2-wide vectors, which the compiler turns into packed v_pk_mul_f32 / v_pk_add_f32: one instruction serves both
+// triangles, and each lane of a packed operation is an ordinary IEEE operation (no contraction: -ffp-contract=off), so every value has
+// the bits tri_test computes.  `two` = false: the second triangle of the record is ignored.
+// The operands come from a pair record (pt_device.h: tripair) — interleaved in memory, so no register moves are needed to form the
+// pairs —, and the per-triangle decisions are straight-line mask arithmetic, in index order exactly as two calls of tri_test:
 //   g_j   triangle j passes the tests of Triangle::hit that do not involve the closest hit so far (det, t >= 0, u, v);
 //   c0    g_0 and t0 / prim0 beat the closest hit on entry;   c1  the same for triangle 1.
 // The reference's leaf box (inline in the pair record) is then evaluated ONCE for most lanes (block A: the box of triangle 0 if c0,
 // else of triangle 1);
 // only a lane where both triangles are candidates goes on to block B, which redoes triangle 1's comparison against
-// the closest hit as triangle 0 left it (in index order, exactly as the loop of tri_test_pair does) and evaluates its box.
+// the closest hit as triangle 0 left it (in index order, exactly as a second call of tri_test would) and evaluates its box.
 // Every floating-point value is produced by the same IEEE operations as in tri_test.
 PT_DEV bool pair_box_ok(const float* rec, bool second, const f3& org, const f3& invD)
 {

@@ -66,7 +66,7 @@ constexpr int kSuspInts = 4 + kWfLdsStack + kWfOvfLevels;
 #define TRACE_TOP_NODES 0
 #endif
 constexpr int kTopNodes = TRACE_TOP_NODES > 0 ? TRACE_TOP_NODES : 1;
-constexpr int kTopStride = 5;         // uint4 per staged node
+[[maybe_unused]] constexpr int kTopStride = 5;         // uint4 per staged node
 
 // block-aggregated append to four lists at once (live streams + one ray queue per kind): one atomicAdd
 // per list per block.  (One atomic per wave was the shade kernel's bottleneck: ~100k returning atomics
@@ -171,16 +171,12 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
     // Stack entry k of this lane: LDS below kWfLdsStack, global memory above (5e-7 of the node steps).  Written as a plain select of
     // the two places the compiler merges them into ONE flat_load (LDS through the texture path, waited for with vmcnt(0), i.e. behind
     // every outstanding store); the empty asm pins the LDS read down as a ds_read of its own.
-#ifdef PT_FLAT_POP      // A/B build
-    auto stack_at = [&](int k) -> int { return (k < kWfLdsStack) ? stack[k * 64] : ovf[(k - kWfLdsStack) * ovfStride]; };
-#else
     auto stack_at = [&](int k) -> int {
         int v = stack[(k < kWfLdsStack ? k : 0) * 64];
         asm volatile("" : "+v"(v));
         if (k >= kWfLdsStack) v = ovf[(k - kWfLdsStack) * ovfStride];
         return v;
     };
-#endif
     // node steps a ray may take in this launch before it is suspended: large launches hide long rays,
     // small (latency-bound) launches must not wait for them
     const int budget = (n >> budgetShift) < (uint32_t)budgetMin ? budgetMin : ((n >> budgetShift) > 1024u ? 1024 : (int)(n >> budgetShift));
@@ -259,21 +255,12 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
 #else
                         const uint32_t q = ((j / kShardBlock) * kWfShards + (uint32_t)shard) * kShardBlock + (j % kShardBlock);
 #endif
-#ifdef PT_KIND_POINTERS      // A/B build: array pointers selected by the ray's kind
-                        const int kind = q < nPath ? 0 : (q < nKind1 ? 1 : 2);
-                        const uint32_t qid = kind == 0 ? b.rq[0][q] : (kind == 1 ? b.rq[1][q - nPath] : b.rq[2][q - nKind1]);
-                        const uint32_t sid = qid & ~kResumeBit;
-                        hs = (uint32_t)kind * n16 + sid;
-                        const float4 o = (kind == 0 ? b.ray_o[0] : (kind == 1 ? b.ray_o[1] : b.ray_o[2]))[sid];
-                        const float4 d = (kind == 0 ? b.ray_d[0] : (kind == 1 ? b.ray_d[1] : b.ray_d[2]))[sid];
-#else
                         const bool k0 = q < nPath, k1 = q < nKind1;                       // kind 0 / kind 0 or 1
                         const uint32_t qid = b.rq[0][q + (k0 ? 0u : (k1 ? n16 - nPath : 2u * n16 - nKind1))];
                         const uint32_t kn = k0 ? 0u : (k1 ? n16 : 2u * n16);              // kind * n16
                         hs = kn + (qid & ~kResumeBit);
                         const float4 o = b.ray_o[0][hs + kn], d = b.ray_d[0][hs + kn];
                         const int kind = k0 ? 0 : 1;      // all that is still asked of it: path ray or not
-#endif
                         org = f3(o.x, o.y, o.z); dir = f3(d.x, d.y, d.z);
                         ray_setup(dir, inv, cscale, degenerate);      // pt_trace.h
                         stopBelow = kind != 0 ? d.w : -__builtin_inff();      // shadow rays: any hit below this t ends the traversal (pt_stream.h: shadow_stop_t)
@@ -371,12 +358,6 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 const float sy = (__builtin_fabsf(By) + 255.f * __builtin_fabsf(Ay)) * kSl;
                 const float sz = (__builtin_fabsf(Bz) + 255.f * __builtin_fabsf(Az)) * kSl;
                 const float Bnx = Bx - sx, Bfx = Bx + sx, Bny = By - sy, Bfy = By + sy, Bnz = Bz - sz, Bfz = Bz + sz;
-#ifdef PT_NODE_SELECT      // A/B build: near / far bytes picked with two selects per axis on one compare
-                const bool px = inv.x >= 0.f, py = inv.y >= 0.f, pz = inv.z >= 0.f;
-                const uint32_t nqx = px ? n2.x : n2.w, fqx = px ? n2.w : n2.x;   // lo.x = n2.x, hi.x = n2.w
-                const uint32_t nqy = py ? n2.y : n3.x, fqy = py ? n3.x : n2.y;   // lo.y = n2.y, hi.y = n3.x
-                const uint32_t nqz = pz ? n2.z : n3.y, fqz = pz ? n3.y : n2.z;   // lo.z = n2.z, hi.z = n3.y
-#else
                 // near / far bytes by the sign of the direction, as a masked swap: on this chip a second v_cndmask on the same vcc costs
                 // ~23 clocks (tools/valu_probe.py), xor / and / arithmetic shift ~2.3 each.  (A zero component of either sign gives
                 // A = B = +-0 on that axis: both planes at t = 0, so either assignment is the same test.)
@@ -385,7 +366,6 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 const uint32_t nqx = n2.x ^ swx, fqx = n2.w ^ swx;   // lo.x = n2.x, hi.x = n2.w
                 const uint32_t nqy = n2.y ^ swy, fqy = n3.x ^ swy;   // lo.y = n2.y, hi.y = n3.x
                 const uint32_t nqz = n2.z ^ swz, fqz = n3.y ^ swz;   // lo.z = n2.z, hi.z = n3.y
-#endif
                 const float cullT = bestT * cscale;
                 int key[4];
 #pragma unroll
@@ -398,16 +378,6 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     const float tfz = __builtin_fmaf((float)((fqz >> (8 * k)) & 0xffu), Az, Bfz);
                     const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.f));
                     const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, cullT));
-#ifdef PT_NODE_KEYSORT      // A/B build: sort keys with the child index in their low bits, select the refs afterwards
-                    key[k] = (tn <= tf) ? ((__float_as_int(tn) & ~3) | k) : 0x7fffffff;   // tn >= 0: its bits order like ints
-                }
-                const int refs[4] = {(int)n1.x, (int)n1.y, (int)n1.z, (int)n1.w};
-                // sort the four keys (5 compare-exchanges); the child index rides in their low bits
-                int k0 = min(key[0], key[1]), k1 = max(key[0], key[1]), k2 = min(key[2], key[3]), k3 = max(key[2], key[3]);
-                { const int a0 = min(k0, k2), a2 = max(k0, k2), a1 = min(k1, k3), a3 = max(k1, k3); k0 = a0; k3 = a3; k1 = min(a1, a2); k2 = max(a1, a2); }
-                auto ref_of = [&](int k) { const int i = k & 3; return i == 0 ? refs[0] : (i == 1 ? refs[1] : (i == 2 ? refs[2] : refs[3])); };
-#define PT_REF(k, r) ref_of(k)
-#else
                     key[k] = (tn <= tf) ? __float_as_int(tn) : 0x7fffffff;   // tn >= 0: its bits order like ints
                 }
                 // sort (entry distance, ref) pairs: 5 compare-exchanges, each one compare + four selects (equal distances: any order will do)
@@ -415,15 +385,12 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
 #define PT_CE(ka, ra, kb, rb) { const bool sw = ka > kb; const int tk = sw ? kb : ka, tr = sw ? rb : ra; kb = sw ? ka : kb; rb = sw ? ra : rb; ka = tk; ra = tr; }
                 PT_CE(k0, r0, k1, r1) PT_CE(k2, r2, k3, r3) PT_CE(k0, r0, k2, r2) PT_CE(k1, r1, k3, r3) PT_CE(k1, r1, k2, r2)
 #undef PT_CE
-#define PT_REF(k, r) (r)
-#endif
                 if (k0 != 0x7fffffff) {
                     // nearest child next; the other hit children go to the stack, farthest first
-                    if (k3 != 0x7fffffff) { const int r = PT_REF(k3, r3); if (sp < kWfLdsStack) stack[sp * 64] = r; else ovf[(sp - kWfLdsStack) * ovfStride] = r; sp++; }
-                    if (k2 != 0x7fffffff) { const int r = PT_REF(k2, r2); if (sp < kWfLdsStack) stack[sp * 64] = r; else ovf[(sp - kWfLdsStack) * ovfStride] = r; sp++; }
-                    if (k1 != 0x7fffffff) { const int r = PT_REF(k1, r1); if (sp < kWfLdsStack) stack[sp * 64] = r; else ovf[(sp - kWfLdsStack) * ovfStride] = r; sp++; }
-                    cur = PT_REF(k0, r0);
-#undef PT_REF
+                    if (k3 != 0x7fffffff) { if (sp < kWfLdsStack) stack[sp * 64] = r3; else ovf[(sp - kWfLdsStack) * ovfStride] = r3; sp++; }
+                    if (k2 != 0x7fffffff) { if (sp < kWfLdsStack) stack[sp * 64] = r2; else ovf[(sp - kWfLdsStack) * ovfStride] = r2; sp++; }
+                    if (k1 != 0x7fffffff) { if (sp < kWfLdsStack) stack[sp * 64] = r1; else ovf[(sp - kWfLdsStack) * ovfStride] = r1; sp++; }
+                    cur = r0;
                 } else if (sp == 0) {
                     cur = kDone;
                 } else {
@@ -442,11 +409,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 const int code = ~pend, first = code >> 3, cnt = code & 7;
                 pend = 0;
                 if (cnt > 0) {
-#ifdef PT_TRI_LOOP      // A/B build: the pair test with a per-triangle loop on the 48-byte records
-                    tri_test_pair(sc, first, cnt > 1, org, dir, inv, degenerate, bestT, bestPrim);
-#else
                     tri_test_pairrec(sc, first, cnt > 1, org, dir, inv, degenerate, bestT, bestPrim);
-#endif
                     if (bestPrim >= 0 && bestT < stopBelow) { cur = kDone; sp = 0; }          // shadow ray: any occluder in front of the light will do
                     else if (cnt > 2) pend = ~(((first + 2) << 3) | (cnt - 2));
                 }
