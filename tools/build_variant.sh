@@ -6,7 +6,7 @@ NAME=$1; EXTRA=$2
 PKG=$(dirname $(dirname $(readlink -f $0)))/pathtrace-on-cuda_amd
 OD=$PKG/build/var_$NAME
 mkdir -p $OD
-FP="-ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt"
+FP="-ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt ${NOSLP--fno-slp-vectorize}"      # NOSLP= (empty) in the environment builds the variant with the SLP vectoriser on
 for f in pt_kernels pt_wavefront pt_api pt_probe pt_comm; do
   # only pt_wavefront depends on the variant flags; reuse the others
   if [ $f = pt_wavefront ] || [ ! -f $OD/$f.o ]; then

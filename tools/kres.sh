@@ -1,7 +1,7 @@
 #!/bin/bash
 # Register / spill / occupancy table of the kernels of one .hip file (compile only, no GPU needed): tools/kres.sh csrc/pt_wavefront.hip [extra flags]
 f=$1; shift
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt --cuda-device-only \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize --cuda-device-only \
   -Rpass-analysis=kernel-resource-usage "$@" -c $f -o /tmp/kres.o 2>&1 | python3 -c "
 import re,sys
 cur=None; rows=[]
