@@ -179,6 +179,7 @@ def main():
                                     max_bounce=cfg["depth"])
 
     tr = TileRenderer(scene, cam, params(args.warmup, args.steps), dev)
+    tr.work.zero_(); tr.tiles.zero_()        # scratch and output buffers are mapped before the timed region (torch.empty leaves first touch to the render)
     warm = TileRenderer(scene, cam, params(0, args.warmup), dev) if args.warmup > 0 else None
 
     def barrier():
