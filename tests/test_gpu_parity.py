@@ -326,6 +326,21 @@ def test_full_frame_1080p_window_parity_and_split():
     assert np.array_equal(bits(frame), bits(full))
 
 
+def test_shading_schedule_switches_inside_a_render():
+    """With the schedule left to the live-stream count (pt_set_shade_rounds(-1)) a 1080p x 3-pass render starts above the switch
+    point (6.2 M streams: one bounce per step) and crosses it as streams retire (two rounds per step): the mix must give the
+    same bits as either pure schedule."""
+    sc = ptamd.Scene.from_prims(ptamd.gen_scene(1, 24))
+    cam = ptamd.make_camera(1920, 1080)
+    prm = ptamd.default_params(passes=3, spp_per_pass=3)
+    frames = []
+    for rounds in (-1, 1, 0):
+        sc.set_shade_rounds(rounds)
+        frames.append(sc.render(cam, prm))
+    assert np.isfinite(frames[0]).all() and frames[0].mean() > 0.05
+    assert np.array_equal(bits(frames[0]), bits(frames[1])) and np.array_equal(bits(frames[0]), bits(frames[2]))
+
+
 def test_error_paths():
     prims = ptamd.gen_scene(0)
     nodes, tris, _ = ptamd.build_bvh(prims[:10])               # drop the light quad -> no emissive triangle
