@@ -45,8 +45,8 @@ constexpr int kWfRefill = 24;        // refill lanes once this many are idle (me
 constexpr int kDone = (int)0x80000000;
 constexpr uint32_t kShardBlock = 2048;   // queue indices per block of the shard interleave (a power of two)
 // wf_trace's waves per SIMD.  7 (72 VGPRs) rather than 8 (64): the two-triangle leaf test needs the room, and
-// the kernel is bound by VALU issue, not by latency hiding (measured: 8 waves with 9 spilled registers and 6 waves
-// with none are both slower).
+// the kernel is bound by VALU issue, not by latency hiding (measured: 8 waves with 6-9 spilled registers and 6 waves
+// with none are both slower; round 2 again: 8 waves +5 % kernel time).
 #ifndef TRACE_WAVES
 #define TRACE_WAVES 7
 #endif
@@ -73,7 +73,7 @@ constexpr int kTopNodes = TRACE_TOP_NODES > 0 ? TRACE_TOP_NODES : 1;
 // per launch on one cache line serialise at ~88 per microsecond; with one atomic per 256-thread block and the
 // counters on separate lines they no longer show.)
 // Must be called by every thread of the block.
-constexpr int kShadeThreads = 1024;      // largest wf_shade workgroup (the default runs 256-thread workgroups, 3 per CU at 146 VGPRs, no spills)
+constexpr int kShadeThreads = 1024;      // largest wf_shade workgroup (the default runs 512-thread workgroups, two per CU: 4 waves/SIMD at 126 VGPRs)
 constexpr int kLists = 1 + kRayKinds;
 template <int N>
 PT_DEV void block_append(const bool (&e)[N], const uint32_t (&id)[N], uint32_t* const (&c)[N], uint32_t* const (&l)[N])
@@ -680,9 +680,9 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     static const int budgetShift = getenv("PTAMD_BS") ? atoi(getenv("PTAMD_BS")) : 14;
     static const int budgetMin = getenv("PTAMD_BM") ? atoi(getenv("PTAMD_BM")) : kWfBudget;
     static const int shadeWaves = getenv("PTAMD_SW") ? atoi(getenv("PTAMD_SW")) : 4;
-    // wf_shade: 4 waves/SIMD (128 VGPRs, 12 of them spilled) in 512-thread workgroups = two per CU (round 2, after sin/cos pairs went through
-    // one sincos: 1462 vs 1418 Msamples/s for 3 waves/SIMD without spills in 256-thread workgroups; other shapes at 4 waves: 384 threads
-    // -13 %, 448 -8 %; at 3 waves: 128 -5 %, 192 -3 %, 384 -23 %)
+    // wf_shade: 4 waves/SIMD (126 VGPRs, nothing spilled since the library is built without the SLP vectoriser) in 512-thread workgroups =
+    // two per CU; other shapes re-measured after that change: 256 threads -4 %, 384 / 768 -13 %, 1024 -8 %, 3 waves/SIMD -9...-13 %
+    // (profiles/r02_experiments/r02_t16_shade_shapes_after_noslp.log)
     static const int shadeThreads = (getenv("PTAMD_ST") && atoi(getenv("PTAMD_ST")) >= 64 && atoi(getenv("PTAMD_ST")) <= kShadeThreads) ? (atoi(getenv("PTAMD_ST")) & ~63) : 512;
     static const int refillMin = getenv("PTAMD_RF") ? atoi(getenv("PTAMD_RF")) : kWfRefill;     // idle lanes that trigger a refill
     static const int triTrig = getenv("PTAMD_TT") ? atoi(getenv("PTAMD_TT")) : 64;
