@@ -52,10 +52,32 @@ def gen_camera_u8():
     print("ref_camera.npz", rot.shape, "ref_u8.npz", vals.shape)
 
 
+def gen_png():
+    """ref_png.npz: small images and the PNG files the REAL srcs/image.cpp (Image(W,H,C) + Image::WriteTo, the reference's own vendored
+    stb_image_write.h) writes for them, through oracle/_ref/ptref pngwrite.  Data: pixels in, file bytes out."""
+    import tempfile
+    rs = np.random.RandomState(777)
+    out = {}
+    for key, (H, W, C) in {"rgb": (21, 37, 3), "gray": (5, 9, 1), "rgba": (8, 8, 4)}.items():
+        px = rs.randint(0, 256, (H, W, C)).astype(np.uint8)
+        px[: H // 2, :, :] = (np.arange(W)[None, :, None] * 7 % 256).astype(np.uint8)      # smooth rows too, so filters / matches get used
+        with tempfile.TemporaryDirectory() as d:
+            q = os.path.join(d, "o.png")
+            O.ref_png_write(px, q)
+            assert np.array_equal(O.ref_png_read(q), px)
+            out[key] = px
+            out[key + "_png"] = np.frombuffer(open(q, "rb").read(), np.uint8)
+    np.savez_compressed(os.path.join(G, "ref_png.npz"), **out)
+    print("ref_png.npz", {k: v.shape for k, v in out.items()})
+
+
 def main():
     os.makedirs(G, exist_ok=True)
     if not O.have_ref():
         raise SystemExit("oracle/_ref/ptref missing: run `make -C oracle ref` first")
+    if len(sys.argv) > 1 and sys.argv[1] == "png":
+        gen_png()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "camera_u8":
         gen_camera_u8()
         return

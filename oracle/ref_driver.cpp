@@ -6,7 +6,8 @@
 //   srcs/CudaPrimitive.cu  (LoadFromBVH flatten; compiled as host C++)
 //   srcs/glad.c            (GL loader table bvh.cpp refers to; never initialised)
 //   srcs/camera.cpp        (Camera::SetRotation / GetForward / GetUp / GetRight)
-//   include/image.h        (ConverToUint8; header-only — srcs/image.cpp needs stb and is not linked)
+//   include/image.h        (ConverToUint8) and srcs/image.cpp (Image::WriteTo / Image(path), with the reference's own vendored
+//                          include/stb_image_write.h / stb_image.h)
 // and the headers include/CudaPrimitive.cuh, CudaVector.cuh, CudaRay.cuh
 // (Triangle::Copy/hit, Sphere::hit, HitResult::SetNormal, vec3, reflect, refract).
 // <cuda_runtime.h> is the REAL header bundled with this image's triton wheel; no CUDA
@@ -244,6 +245,31 @@ static int cmd_u8(int argc, char** argv)
     return 0;
 }
 
+// pngwrite in.bin W H C out.png : W*H*C bytes -> PNG through the reference's Image(W,H,C) + Image::WriteTo (srcs/image.cpp:17-25)
+static int cmd_pngwrite(int argc, char** argv)
+{
+    if (argc != 7) return 1;
+    std::vector<unsigned char> in = slurp(argv[2]);
+    const int W = atoi(argv[3]), H = atoi(argv[4]), C = atoi(argv[5]);
+    if (in.size() != (size_t)W * H * C) { fprintf(stderr, "ptref: pngwrite size mismatch\n"); return 2; }
+    Image img(W, H, C);
+    memcpy(img.GetData(), in.data(), in.size());
+    return img.WriteTo(argv[6]) ? 0 : 3;
+}
+
+// pngread in.png out.bin : decode through the reference's Image(path) (stbi_load, srcs/image.cpp:12-15); out = W H C (int32) + pixels
+static int cmd_pngread(int argc, char** argv)
+{
+    if (argc != 4) return 1;
+    Image img(argv[2]);
+    if (!img.GetData()) { fprintf(stderr, "ptref: cannot decode %s\n", argv[2]); return 3; }
+    const int hdr[3] = {img.GetWidth(), img.GetHeight(), img.GetNrChannels()};
+    std::vector<unsigned char> out((const unsigned char*)hdr, (const unsigned char*)hdr + 12);
+    out.insert(out.end(), img.GetData(), img.GetData() + (size_t)hdr[0] * hdr[1] * hdr[2]);
+    spit(argv[3], out.data(), out.size());
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     int rc = 1;
@@ -256,7 +282,9 @@ int main(int argc, char** argv)
         else if (c == "sizes") rc = cmd_sizes();
         else if (c == "camera") rc = cmd_camera(argc, argv);
         else if (c == "u8") rc = cmd_u8(argc, argv);
+        else if (c == "pngwrite") rc = cmd_pngwrite(argc, argv);
+        else if (c == "pngread") rc = cmd_pngread(argc, argv);
     }
-    if (rc == 1) fprintf(stderr, "usage: ptref bvh|trihit|sphit|vecmath|sizes|camera|u8 ...\n");
+    if (rc == 1) fprintf(stderr, "usage: ptref bvh|trihit|sphit|vecmath|sizes|camera|u8|pngwrite|pngread ...\n");
     return rc;
 }

@@ -272,3 +272,27 @@ def ref_u8(values):
     """ConverToUint8 of the real include/image.h."""
     (o,) = _run_ref("u8", [np.ascontiguousarray(values, np.float32)], [np.uint8])
     return o
+
+
+PTVIEWER = os.path.join(ORACLE_DIR, "_ref", "ptviewer")
+BINDING_OBJ = os.path.join(ORACLE_DIR, "_ref", "pathtracer_mi355x.obj")
+
+
+def ref_png_write(pixels_hwc, path):
+    """PNG through the reference's Image(W,H,C) + Image::WriteTo — real srcs/image.cpp with its vendored stb_image_write.h."""
+    px = np.ascontiguousarray(pixels_hwc, np.uint8)
+    H, W, C = px.shape
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "in.bin")
+        px.tofile(p)
+        subprocess.run([PTREF, "pngwrite", p, str(W), str(H), str(C), path], check=True, stderr=subprocess.DEVNULL)
+
+
+def ref_png_read(path):
+    """Decode through the reference's Image(path) (stbi_load, srcs/image.cpp:12-15).  Returns (H, W, C) uint8."""
+    with tempfile.TemporaryDirectory() as d:
+        o = os.path.join(d, "out.bin")
+        subprocess.run([PTREF, "pngread", path, o], check=True, stderr=subprocess.DEVNULL)
+        raw = np.fromfile(o, np.uint8)
+    W, H, C = (int(v) for v in raw[:12].view(np.int32))
+    return raw[12:].reshape(H, W, C)
