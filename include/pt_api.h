@@ -191,6 +191,12 @@ PT_API int  pt_render_timings(PtScene* s, float* ms_out, int32_t cap, int32_t re
 typedef struct PtComm PtComm;
 PT_API int  pt_comm_unique_id(uint8_t id[PT_COMM_ID_BYTES]);
 PT_API int  pt_comm_create(const uint8_t id[PT_COMM_ID_BYTES], int32_t rank, int32_t world, int32_t device, PtComm** out);
+/* Rendezvous through a file for the processes of one node: rank 0 removes any file at `path`, writes { world, job_tag, id },
+ * joins and removes the file again; ranks > 0 wait (timeout_s) for a file carrying THEIR world and job_tag — the file of an
+ * earlier job is ignored.  job_tag = any value the ranks of one job share and other jobs do not (launcher pid, job id).
+ * pt_comm_create_from_file = the same with job_tag 0.  ncclCommInitRank itself has no timeout: a rank that never arrives
+ * leaves the others waiting in it, as with any RCCL program. */
+PT_API int  pt_comm_create_from_file_tagged(const char* path, uint64_t job_tag, int32_t rank, int32_t world, int32_t device, int32_t timeout_s, PtComm** out);
 PT_API int  pt_comm_create_from_file(const char* path, int32_t rank, int32_t world, int32_t device, int32_t timeout_s, PtComm** out);
 PT_API void pt_comm_destroy(PtComm* c);
 PT_API int32_t pt_comm_rank(const PtComm* c);
@@ -200,7 +206,9 @@ PT_API int  pt_gather_tiles(PtComm* c, const float* d_tiles, int64_t n_floats, f
 PT_API int  pt_gather_frame(PtComm* c, const float* d_tiles, const PtCamera* cam, const PtParams* prm,
                             float* d_gathered, float* d_frame_rgb, void* hip_stream);
 /* The multi-GPU sibling of pt_render for hosts without HIP code of their own: this rank's tiles, the gather, and on rank 0 the
- * assembled frame in h_accum_rgb[W*H*3] (ignored elsewhere).  Rank and world come from the communicator.  Synchronous. */
+ * assembled frame in h_accum_rgb[W*H*3] (ignored elsewhere).  Rank and world come from the communicator; the scene must live on the
+ * communicator's device.  Synchronous.  Before the gather the ranks exchange a 4-byte status (max all-reduce): if ANY rank failed to
+ * render its tiles, EVERY rank returns an error and nobody waits in the gather. */
 PT_API int  pt_render_split(PtScene* s, const PtCamera* cam, const PtParams* prm, PtComm* c, float* h_accum_rgb);
 
 /* ----------------------------------------------------------------------------------
@@ -279,12 +287,13 @@ PT_API int  pt_dbg_trace_timeline(PtScene* s, int64_t* out3n, int32_t n_launches
  * Both produce bit-identical frames.  Environment PTAMD_MODE overrides the default.
  * pt_last_iterations: bounce iterations the pipeline needed for the last render. */
 PT_API int  pt_set_mode(PtScene* s, int32_t mode);
-/* Per-launch timing of the traversal kernel (wf_trace, mode 1): pt_enable_trace_timing makes
- * every following render record a HIP event pair, on the launch stream, around each of its
- * first max_launches wf_trace launches (0 = off); pt_trace_timing returns their summed and
- * maximum duration in ms and how many launches were timed in the last render. */
+/* Per-launch timing of the two pipeline kernels (mode 1): pt_enable_trace_timing makes every following render record HIP
+ * events, on the launch stream, before and after each of its first max_launches wf_trace launches and after the wf_shade
+ * launch that follows it (0 = off); pt_trace_timing / pt_shade_timing return the summed and maximum duration in ms of the
+ * wf_trace / wf_shade launches so bracketed, and how many were timed in the last render. */
 PT_API int  pt_enable_trace_timing(PtScene* s, int32_t max_launches);
 PT_API int  pt_trace_timing(PtScene* s, double* sum_ms, int32_t* launches, double* max_ms);
+PT_API int  pt_shade_timing(PtScene* s, double* sum_ms, int32_t* launches, double* max_ms);
 PT_API int  pt_last_iterations(PtScene* s);
 /* Mode 1 hands the last streams of a render to one run-to-completion launch (wf_drain) once at
  * most `live_streams` are still alive (0 = never, the default: on MI355X the drain launch measured

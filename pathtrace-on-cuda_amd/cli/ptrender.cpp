@@ -1,6 +1,7 @@
 // ptrender — headless command line for the path tracer (the reference has no CLI: its window size
 // is a compile-time constant and rendering starts on key P, srcs/main.cpp:15-16, srcs/renderer.cpp:283-293).
 // Uses only the reference-shaped host surface (host/ref_surface.h).
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,7 +16,8 @@ static void usage()
         "usage: ptrender [--scene cornell|standin|standin4] [--obj FILE --obj-scale S --obj-translate X,Y,Z]\n"
         "                [--glass-sphere] [--width W] [--height H] [--passes N] [--spp N] [--depth N]\n"
         "                [--lat-lon N] [--device D] [--no-progressive] [--raw FILE]\n"
-        "                [--world N --rank R --id-file PATH]   (one process per GPU; rank 0 writes the frame)\n"
+        "                [--world N --rank R --id-file PATH [--job-tag T]]   (one process per GPU; rank 0 writes the frame;\n"
+        "                 T = a number the ranks of this job share and other jobs do not, default: the parent process id)\n"
         "Writes temp.png (per pass) and result.png in the current directory, like PathTracer::Render.\n"
         "--raw FILE: also writes the float accumulation buffer (W*H*3 float32) there after every pass (viewer hook).\n"
         "Defaults: scene cornell, 1920x1080, 8 passes x 64 spp, depth 8.\n";
@@ -27,7 +29,7 @@ int main(int argc, char** argv)
     float objScale = 1.f; float objT[3] = {0, 0, 0};
     int W = 1920, H = 1080, passes = 8, spp = 64, depth = 8, latlon = 187, device = 0;
     bool glass = false, progressive = true;
-    int rank = 0, world = 1; std::string idFile;
+    int rank = 0, world = 1; std::string idFile; unsigned long long jobTag = (unsigned long long)getppid();
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> const char* { if (i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };
@@ -48,6 +50,7 @@ int main(int argc, char** argv)
         else if (a == "--world") world = atoi(next());
         else if (a == "--rank") rank = atoi(next());
         else if (a == "--id-file") idFile = next();
+        else if (a == "--job-tag") jobTag = strtoull(next(), nullptr, 10);
         else if (a == "--help" || a == "-h") { usage(); return 0; }
         else { std::cerr << "unknown option " << a << "\n"; usage(); return 2; }
     }
@@ -77,7 +80,7 @@ int main(int argc, char** argv)
     PathTracer tracer;
     tracer.params.passes = passes; tracer.params.spp_per_pass = spp; tracer.params.max_bounce = depth;
     tracer.device = device; tracer.progressive = progressive; tracer.raw_path = rawPath;
-    tracer.rank = rank; tracer.world = world; tracer.id_file = idFile;
+    tracer.rank = rank; tracer.world = world; tracer.id_file = idFile; tracer.job_tag = jobTag;
     tracer.Render(camera, &bvh);
     const double samples = (double)W * H * passes * spp;
     std::cout << "{\"msamples_per_s_kernel\": " << samples / (tracer.last_render_ms * 1e-3) / 1e6 << ", \"kernel_ms\": " << tracer.last_render_ms << "}" << std::endl;

@@ -55,7 +55,7 @@ struct PtScene {
     ptd::DevScene dev{};
     void* d_nodes = nullptr; void* d_quad = nullptr; void* d_tri = nullptr; void* d_tripair = nullptr; void* d_leafbox = nullptr;
     void* d_surf = nullptr;
-    void* d_lights = nullptr; void* d_spheres = nullptr;
+    void* d_lights = nullptr; void* d_spheres = nullptr; void* d_lobe = nullptr;
     unsigned int* d_unit_counter = nullptr;
     void* d_counters = nullptr;
     int64_t bytes = 0;
@@ -206,6 +206,14 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     auto okE = [](const float* e) { return std::isfinite(e[0]) && std::isfinite(e[1]) && std::isfinite(e[2]) && e[0] >= 0.f && e[1] >= 0.f && e[2] >= 0.f; };
     for (int i = 0; i < n_tris; i++) emitOk = emitOk && okE(tris[i].mat0.emittance);
     for (int i = 0; i < n_spheres; i++) emitOk = emitOk && okE(spheres[i].mat.emittance);
+    // lobe per primitive (the branch of include/CudaUtil.cuh:247-270 as pt_bxdf.h: lobe_of takes it): a scheduling hint for wf_shade
+    std::vector<uint8_t> lobe((size_t)n_tris + (size_t)n_spheres);
+    auto lobeOf = [](const PtMaterial& m) -> uint8_t {
+        if (m.opacity < (1.f - 0.0001f)) return (m.roughness < 1e-2f) ? 3 : 2;
+        return (m.roughness < 1e-2f) ? 1 : 0;
+    };
+    for (int i = 0; i < n_tris; i++) lobe[(size_t)i] = lobeOf(tris[i].mat0);
+    for (int i = 0; i < n_spheres; i++) lobe[(size_t)n_tris + (size_t)i] = lobeOf(spheres[i].mat);
     std::vector<float> sph((size_t)n_spheres * 16);
     for (int i = 0; i < n_spheres; i++) {
         const PtSphere& s = spheres[i];
@@ -227,7 +235,8 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
         (rc = upload(&sc->d_leafbox, accel.leafbox.data(), accel.leafbox.size() * 4, sc->bytes)) ||
         (rc = upload(&sc->d_surf, surf.data(), surf.size() * 4, sc->bytes)) ||
         (rc = upload(&sc->d_lights, lights.data(), lights.size() * 4, sc->bytes)) ||
-        (rc = upload(&sc->d_spheres, sph.data(), sph.size() * 4, sc->bytes))) {
+        (rc = upload(&sc->d_spheres, sph.data(), sph.size() * 4, sc->bytes)) ||
+        (rc = upload(&sc->d_lobe, lobe.data(), lobe.size(), sc->bytes))) {
         pt_scene_destroy(sc);
         return rc;
     }
@@ -259,6 +268,7 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     sc->dev.leafbox = (const float4*)sc->d_leafbox; sc->dev.surf = (const float4*)sc->d_surf;
     sc->dev.lights = (const float4*)sc->d_lights; sc->dev.spheres = (const float4*)sc->d_spheres;
     sc->dev.n_quad = accel.n_quad;
+    sc->dev.lobe = (const uint8_t*)sc->d_lobe;
     sc->dev.nee_prune = (emitOk && !(getenv("PTAMD_PRUNE") && atoi(getenv("PTAMD_PRUNE")) == 0)) ? 1 : 0;      // PTAMD_PRUNE=0: A/B only
     sc->dev.n_nodes = n_wide; sc->dev.n_tris = n_tris; sc->dev.n_lights = n_lights; sc->dev.n_spheres = n_spheres;
     *out = sc;
@@ -269,7 +279,7 @@ void pt_scene_destroy(PtScene* s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* p[] = {s->d_nodes, s->d_quad, s->d_tri, s->d_tripair, s->d_leafbox, s->d_surf, s->d_lights, s->d_spheres, s->d_unit_counter, s->d_counters};
+    void* p[] = {s->d_nodes, s->d_quad, s->d_tri, s->d_tripair, s->d_leafbox, s->d_surf, s->d_lights, s->d_spheres, s->d_lobe, s->d_unit_counter, s->d_counters};
     for (void* q : p) if (q) (void)hipFree(q);
     for (int i = 0; i < PtScene::kEvRing; i++) for (int j = 0; j < 2; j++) if (s->ev[i][j]) (void)hipEventDestroy(s->ev[i][j]);
     if (s->h_poll) (void)hipHostFree(s->h_poll);
@@ -280,6 +290,7 @@ void pt_scene_destroy(PtScene* s)
 }
 
 int32_t pt_scene_num_lights(const PtScene* s) { return s ? s->n_lights : 0; }
+__attribute__((visibility("hidden"))) int ptk_scene_device(const PtScene* s) { return s ? s->device : -1; }      // for pt_comm.hip
 int64_t pt_scene_device_bytes(const PtScene* s) { return s ? s->bytes : 0; }
 
 // persistent grid of the traversal kernel: 256 CUs x 7 blocks of 4 waves = 7 waves/SIMD, what its 72 VGPRs allow
@@ -362,14 +373,14 @@ int pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm, float*
         // queue-driven pipeline (pt_wavefront.hip); polls the live-stream count, so it returns once the render has drained
         int iters = 0;
         const int C = ptk_wf_cohorts((size_t)d.n_units);
-        s->trace_ev_per = s->trace_ev.empty() ? 0 : (int)(s->trace_ev.size() / 2) / C;
+        s->trace_ev_per = s->trace_ev.empty() ? 0 : (int)(s->trace_ev.size() / 3) / C;
         for (int k = 0; k < 4; k++) s->trace_ev_used[k] = 0;
         // diagnostic (PTAMD_TSTAT=1): wf_trace counts its trips and the lanes they serve; read with pt_last_counters
         static const bool kTraceStat = getenv("PTAMD_TSTAT") && atoi(getenv("PTAMD_TSTAT")) != 0;
         if (kTraceStat) HIPCHK(hipMemsetAsync(s->d_counters, 0, kCounterBytes, stream));
         HIPCHK(ptk_wf_render(s->device, &s->dev, &c, &d, d_work, kTraceBlocks, s->h_poll, stream, s->xstreams,
                              s->ev[slot][0], s->ev[slot][1], s->ev_fork, s->ev_join, &iters,
-                             s->trace_ev.empty() ? nullptr : s->trace_ev.data(), (int)s->trace_ev.size() / 2, s->trace_ev_used, s->drain_below, s->shade_rounds,
+                             s->trace_ev.empty() ? nullptr : s->trace_ev.data(), (int)s->trace_ev.size() / 3, s->trace_ev_used, s->drain_below, s->shade_rounds,
                              kTraceStat ? s->d_counters : nullptr));
         s->last_iters = iters;
         s->ev_count++;
@@ -464,20 +475,20 @@ PT_API int pt_enable_trace_timing(PtScene* s, int32_t max_launches)
     if (!s || max_launches < 0 || max_launches > (1 << 20)) { pt_set_error("pt_enable_trace_timing: bad argument"); return PT_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     for (hipEvent_t e : s->trace_ev) (void)hipEventDestroy(e);
-    s->trace_ev.assign((size_t)max_launches * 2, nullptr);
+    s->trace_ev.assign((size_t)max_launches * 3, nullptr);
     for (auto& e : s->trace_ev) HIPCHK(hipEventCreate(&e));
     for (int k = 0; k < 4; k++) s->trace_ev_used[k] = 0;
     return PT_OK;
 }
-PT_API int pt_trace_timing(PtScene* s, double* sum_ms, int32_t* launches, double* max_ms)
+static int kernel_timing(PtScene* s, int first, double* sum_ms, int32_t* launches, double* max_ms)
 {
-    if (!s || !sum_ms || !launches) { pt_set_error("pt_trace_timing: NULL"); return PT_ERR_INVALID; }
+    if (!s || !sum_ms || !launches) { pt_set_error("pt_trace_timing / pt_shade_timing: NULL"); return PT_ERR_INVALID; }
     HIPCHK(hipSetDevice(s->device));
     double sum = 0, mx = 0;
     int total = 0;
     for (int c = 0; c < 4; c++)
         for (int i = 0; i < s->trace_ev_used[c]; i++) {
-            const size_t k = ((size_t)c * s->trace_ev_per + i) * 2;
+            const size_t k = ((size_t)c * s->trace_ev_per + i) * 3 + (size_t)first;
             float ms = 0.f;
             HIPCHK(hipEventSynchronize(s->trace_ev[k + 1]));
             HIPCHK(hipEventElapsedTime(&ms, s->trace_ev[k], s->trace_ev[k + 1]));
@@ -487,6 +498,8 @@ PT_API int pt_trace_timing(PtScene* s, double* sum_ms, int32_t* launches, double
     *sum_ms = sum; *launches = total; if (max_ms) *max_ms = mx;
     return PT_OK;
 }
+PT_API int pt_trace_timing(PtScene* s, double* sum_ms, int32_t* launches, double* max_ms) { return kernel_timing(s, 0, sum_ms, launches, max_ms); }
+PT_API int pt_shade_timing(PtScene* s, double* sum_ms, int32_t* launches, double* max_ms) { return kernel_timing(s, 1, sum_ms, launches, max_ms); }
 PT_API int pt_set_mode(PtScene* s, int32_t mode) { if (!s || mode < 0 || mode > 1) { pt_set_error("pt_set_mode: mode must be 0 or 1"); return PT_ERR_INVALID; } s->mode = mode; return PT_OK; }
 PT_API int pt_last_iterations(PtScene* s) { return s ? s->last_iters : -1; }
 PT_API int pt_set_drain_threshold(PtScene* s, int32_t live_streams)

@@ -126,6 +126,7 @@ struct SState {
 // cosA / denom until the shadow ray is back), the BSDF sample and the roulette.  Leaves the shadow ray in st.sh* and,
 // unless the path ends here (returns true), the next path ray in st.pathO / pathD.
 // ---------------------------------------------------------------------------------------
+template <int LOBE = -1>      // LOBE >= 0: the caller knows the hit's lobe (lobe-sorted launches, wf_bounce); -1: read it from the material
 PT_DEV bool bounce(const DevScene& sc, const DevParams& prm, int prim, float t, const f3& rorg, const f3& rdir,
                    SState& st, bool& bRefracted, bool& neeOk, bool& needShadow)
 {
@@ -134,7 +135,7 @@ PT_DEV bool bounce(const DevScene& sc, const DevParams& prm, int prim, float t, 
     else surf_sphere(sc, prim - sc.n_tris, t, rorg, rdir, s);
     if (sqlen(s.m.emittance) > kEps) st.radiance += st.weight * s.m.emittance;   // :220-224
     const float ior = ior_of(s.m);                                          // :231
-    const int lobe = lobe_of(s.m);
+    const int lobe = LOBE >= 0 ? LOBE : lobe_of(s.m);
     const f3 wo = -rdir;
     // NEE sample (:235-245, SamplePrimitive :38-48)
     const NeeSample ns = nee_sample(sc, st.rng, s.p);
@@ -194,7 +195,7 @@ PT_DEV bool bounce(const DevScene& sc, const DevParams& prm, int prim, float t, 
 
 // Returns true when the stream has added its last sample to the pixel.  On return st.flags
 // describes the rays to trace next and the ray fields hold them.
-template <bool TWO>
+template <bool TWO, int LOBE = -1>
 PT_DEV bool shade_step_t(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const WfBuf& b, uint32_t sid, SState& st,
                          float2 hitP, float2 hitS, float2 hitA)
 {
@@ -279,7 +280,7 @@ PT_DEV bool shade_step_t(const DevScene& sc, const DevCamera& cam, const DevPara
         }
         if (go) {
             bool needSh;
-            const bool terminate = bounce(sc, prm, prim, t, rorg, rdir, st, bRefracted, neeCur, needSh);
+            const bool terminate = bounce<LOBE>(sc, prm, prim, t, rorg, rdir, st, bRefracted, neeCur, needSh);
             shCur = needSh;
             if (!terminate) { pathCur = true; closing = false; }
             else {
@@ -337,7 +338,7 @@ PT_DEV bool shade_step_t(const DevScene& sc, const DevCamera& cam, const DevPara
         }
         if (go) {
             bool needSh;
-            const bool terminate = bounce(sc, prm, prim, t, rorg, rdir, st, bRefracted, neeCur, needSh);
+            const bool terminate = bounce<LOBE>(sc, prm, prim, t, rorg, rdir, st, bRefracted, neeCur, needSh);
             shCur = needSh;
             if (!terminate) { pathCur = true; closing = false; }
             else {

@@ -461,7 +461,13 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
 // ---------------------------------------------------------------------------------------
 // wf_shade: one thread per live stream, one bounce.
 // ---------------------------------------------------------------------------------------
-template <int WAVES, bool TWO>
+// SORT (round 3): the streams of a workgroup are re-dealt to its lanes by the lobe of the bounce they are about to shade (the reference's
+// 4-way branch, CudaUtil.cuh:247-334), so that a wave runs one lobe's code instead of all of them under masks: a stable counting
+// sort of the workgroup's <= 1024 list entries through LDS (class = lobe 0..3 | 4 no bounce this step | 5 no stream), each lane then
+// shades the stream it was dealt, and the outcome goes back through LDS to the lane that owns the entry, which does the appends —
+// so every list keeps the order of the live list (stream order) exactly as without the sort.  The class only steers scheduling (it
+// comes from DevScene::lobe, a byte per primitive); the bounce itself still reads the lobe from the material.  Result-neutral.
+template <int WAVES, bool TWO, bool SORT = false>
 __global__ __launch_bounds__(WAVES * 256, WAVES)
 void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, int slotOut, int slotClear, int listIn)
 {
@@ -469,11 +475,55 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
     if (blockIdx.x == 0) for (int k = threadIdx.x; k < kWfSlotBytes / 4; k += blockDim.x) ((uint32_t*)&b.cnt[slotClear])[k] = 0;
     if ((uint32_t)blockIdx.x * blockDim.x >= nIn) return;
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool have = idx < nIn;
+    bool have = idx < nIn;
     bool alive = false, emit[kRayKinds] = {false, false, false};
     uint32_t sid = 0, resume = 0;      // resume: the queued rays are suspended traversals (wf_trace then reads their records)
+    uint32_t mySid = 0;                // SORT: the stream of this lane's own list entry (what it appends)
+    [[maybe_unused]] __shared__ uint32_t s_sid[SORT ? kShadeThreads : 1];
+    [[maybe_unused]] __shared__ uint16_t s_src[SORT ? kShadeThreads : 1];
+    [[maybe_unused]] __shared__ uint32_t s_res[SORT ? kShadeThreads : 1];
+    [[maybe_unused]] __shared__ uint32_t s_cls[SORT ? 6 * (kShadeThreads / 64) : 1];
+    [[maybe_unused]] uint32_t src = threadIdx.x;
+    if (have) sid = b.active[listIn][idx];
+    if constexpr (SORT) {
+        mySid = sid;
+        // ---- class of this entry's step: which lobe its bounce will run (pt_stream.h: shade_step_t decides the same way) ----
+        int cls = 5;
+        if (have) {
+            const uint4 r1 = b.rng1[sid];
+            const uint32_t fl = r1.w;
+            const float2 hP = b.hit[0][sid], hS = b.hit[1][sid], hA = b.hit[2][sid];
+            const int pP = (fl & F_PATH) ? __float_as_int(hP.y) : -1, pS = (fl & F_SHADOW) ? __float_as_int(hS.y) : -1, pA = (fl & F_SHADOWA) ? __float_as_int(hA.y) : -1;
+            cls = 4;
+            if (!(pP <= -2 || pS <= -2 || pA <= -2)) {
+                int prim = -1;
+                bool cur = (fl & F_CUR) != 0;
+                if (!(fl & F_PRIMARY) && !(fl & F_PATH) && cur) cur = false;
+                if ((fl & F_PATH) && !(fl & F_PRIMARY)) { prim = pP; if (prim < 0) cur = false; }
+                if (prim < 0 && !cur && (r1.z >> 16) > 0) prim = (fl & F_PRIMARY) ? pP : __float_as_int(b.hit0[sid].y);
+                if (prim >= 0) cls = sc.lobe[prim];
+            }
+        }
+        // ---- stable counting sort of the workgroup's entries by class ----
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) { const unsigned long long m = __ballot(cls == c); if (cls == c) mine = m; if (lane == 0) s_cls[c * (kShadeThreads / 64) + wave] = (uint32_t)__builtin_popcountll(m); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (int c = 0; c < 6; c++) for (int w = 0; w < nw; w++) { const uint32_t v = s_cls[c * (kShadeThreads / 64) + w]; s_cls[c * (kShadeThreads / 64) + w] = run; run += v; }
+        }
+        __syncthreads();
+        const uint32_t pos = s_cls[cls * (kShadeThreads / 64) + wave] + (uint32_t)__builtin_popcountll(mine & ((1ull << lane) - 1ull));
+        s_sid[pos] = have ? sid : 0xffffffffu;
+        s_src[pos] = (uint16_t)threadIdx.x;
+        __syncthreads();
+        sid = s_sid[threadIdx.x]; src = s_src[threadIdx.x];
+        have = sid != 0xffffffffu;
+        if (!have) sid = 0;
+    }
     if (have) {
-        sid = b.active[listIn][idx];
         SState st;
         const float2 hitP = b.hit[0][sid], hitS = b.hit[1][sid], hitA = b.hit[2][sid];      // same fetch level as the state
         load_state(b, sid, st);
@@ -493,6 +543,14 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
                 emit[0] = (nf & F_PATH) != 0; emit[1] = (nf & F_SHADOW) != 0; emit[2] = (nf & F_SHADOWA) != 0;
             }
         }
+    }
+    if constexpr (SORT) {
+        // the outcome goes back to the lane that owns the list entry
+        s_res[src] = (alive ? 1u : 0u) | (emit[0] ? 2u : 0u) | (emit[1] ? 4u : 0u) | (emit[2] ? 8u : 0u) | (resume ? 16u : 0u);
+        __syncthreads();
+        const uint32_t r = s_res[threadIdx.x];
+        alive = (r & 1u) != 0; emit[0] = (r & 2u) != 0; emit[1] = (r & 4u) != 0; emit[2] = (r & 8u) != 0; resume = (r & 16u) ? kResumeBit : 0u;
+        sid = mySid;
     }
     const bool e[kLists] = {alive, emit[0], emit[1], emit[2]};
     uint32_t* const c[kLists] = {&b.cnt[slotOut].nActive, &b.cnt[slotOut].nRays[0][0], &b.cnt[slotOut].nRays[1][0], &b.cnt[slotOut].nRays[2][0]};
@@ -684,6 +742,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     // two per CU; other shapes re-measured after that change: 256 threads -4 %, 384 / 768 -13 %, 1024 -8 %, 3 waves/SIMD -9...-13 %
     // (profiles/r02_experiments/r02_t16_shade_shapes_after_noslp.log)
     static const int shadeThreads = (getenv("PTAMD_ST") && atoi(getenv("PTAMD_ST")) >= 64 && atoi(getenv("PTAMD_ST")) <= kShadeThreads) ? (atoi(getenv("PTAMD_ST")) & ~63) : 512;
+    static const bool shadeSort = getenv("PTAMD_SORT") && atoi(getenv("PTAMD_SORT")) != 0;      // wf_shade: lanes re-dealt by lobe inside a workgroup
     static const int refillMin = getenv("PTAMD_RF") ? atoi(getenv("PTAMD_RF")) : kWfRefill;     // idle lanes that trigger a refill
     static const int triTrig = getenv("PTAMD_TT") ? atoi(getenv("PTAMD_TT")) : 64;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
@@ -704,18 +763,20 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
         for (int k = 0; k < poll; k++, it++) {
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
             const bool timed = trace_ev && it < trace_ev_pairs;
-            if (timed) (void)hipEventRecord(trace_ev[2 * it], stream);
+            if (timed) (void)hipEventRecord(trace_ev[3 * it], stream);
             if (traceStat && traceStatClk) hipLaunchKernelGGL(wf_trace<3>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
             else if (traceStat && traceStatFull) hipLaunchKernelGGL(wf_trace<1>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
             else if (traceStat) hipLaunchKernelGGL(wf_trace<2>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
             else hipLaunchKernelGGL(wf_trace<0>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, 0);
-            if (timed) (void)hipEventRecord(trace_ev[2 * it + 1], stream);
+            if (timed) (void)hipEventRecord(trace_ev[3 * it + 1], stream);
             const dim3 sg((liveBound + shadeThreads - 1) / shadeThreads), sb(shadeThreads);
             const bool twoRounds = shadeRounds >= 0 ? (shadeRounds != 0) : (liveBound < trStreams);
-#define PT_SHADE(W, T) hipLaunchKernelGGL((wf_shade<W, T>), sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1)
-            if (twoRounds) { if (shadeWaves == 2) PT_SHADE(2, true); else if (shadeWaves == 3) PT_SHADE(3, true); else PT_SHADE(4, true); }
-            else { if (shadeWaves == 2) PT_SHADE(2, false); else if (shadeWaves == 3) PT_SHADE(3, false); else PT_SHADE(4, false); }
+#define PT_SHADE(W, T, S) hipLaunchKernelGGL((wf_shade<W, T, S>), sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1)
+            if (shadeSort) { if (twoRounds) PT_SHADE(4, true, true); else PT_SHADE(4, false, true); }
+            else if (twoRounds) { if (shadeWaves == 2) PT_SHADE(2, true, false); else if (shadeWaves == 3) PT_SHADE(3, true, false); else PT_SHADE(4, true, false); }
+            else { if (shadeWaves == 2) PT_SHADE(2, false, false); else if (shadeWaves == 3) PT_SHADE(3, false, false); else PT_SHADE(4, false, false); }
 #undef PT_SHADE
+            if (timed) (void)hipEventRecord(trace_ev[3 * it + 2], stream);      // [3it+1, 3it+2] brackets this iteration's wf_shade
         }
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(h_cnt, &b.cnt[it % 3].nActive, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
@@ -741,7 +802,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
 // Runs the whole pipeline for one pt_render_tiles call.  `stream` is the caller's stream;
 // `xstreams` are up to 3 extra streams owned by the scene; `h_cnt` holds one pinned poll word
 // (64 B apart) per cohort.  ev_begin/ev_end bracket the whole render on `stream`.  trace_ev:
-// optional event pairs, split evenly between cohorts; trace_ev_used[c] = pairs used by cohort c.
+// optional event triples (before wf_trace, after it, after wf_shade), split evenly between cohorts; trace_ev_used[c] = triples used by cohort c.
 // Blocks the host until the render has drained.
 hipError_t ptk_wf_render(int device, const ptd::DevScene* sc, const ptd::DevCamera* cam, const ptd::DevParams* prm,
                          void* work, int traceBlocks, uint32_t* h_cnt, hipStream_t stream, hipStream_t* xstreams,
@@ -770,7 +831,7 @@ hipError_t ptk_wf_render(int device, const ptd::DevScene* sc, const ptd::DevCame
         b.staging = staging + u0 * 64 * 3;
         hipStream_t cs = (c == 0) ? stream : xstreams[c - 1];
         if (c > 0) { if ((e = hipStreamWaitEvent(cs, ev_fork, 0)) != hipSuccess) return e; }
-        hipEvent_t* tev = trace_ev ? trace_ev + (size_t)2 * evPer * c : nullptr;
+        hipEvent_t* tev = trace_ev ? trace_ev + (size_t)3 * evPer * c : nullptr;
         int* used = trace_ev_used ? &trace_ev_used[c] : nullptr;
         if (cp.n_units == 0) { if (used) *used = 0; continue; }
         auto job = [=, &rc, &iters]() { rc[(size_t)c] = run_cohort(device, sc, cam, cp, b, traceBlocks, h_cnt + 16 * c, cs, tev, evPer, used, drainBelow, shadeRounds, &iters[(size_t)c], (unsigned long long*)traceStat); };

@@ -115,8 +115,13 @@ void PathTracer::Render(Camera& camera, BVH* bvh)
     if (world > 1) {
         // one process per GPU: this rank's tiles for all passes, one gather (RCCL), frame on rank 0
         PtComm* comm = nullptr;
-        check(pt_comm_create_from_file(id_file.c_str(), rank, world, device, 120, &comm), "pt_comm_create_from_file");
-        check(pt_render_split(scene, &cam, &params, comm, raw.data()), "pt_render_split");
+        check(pt_comm_create_from_file_tagged(id_file.c_str(), job_tag, rank, world, device, 120, &comm), "pt_comm_create_from_file_tagged");
+        if (pt_render_split(scene, &cam, &params, comm, raw.data()) != PT_OK) {
+            // every rank gets an error when any rank failed (status exchange before the gather): nobody is left in a collective
+            std::cerr << "GPU error in pt_render_split (rank " << rank << ") : " << pt_last_error() << std::endl;
+            pt_comm_destroy(comm); pt_scene_destroy(scene);
+            exit(99);
+        }
         float ms = 0.f; pt_last_render_ms(scene, &ms); last_render_ms = ms;
         pt_comm_destroy(comm);
         if (rank != 0) { pt_scene_destroy(scene); return; }

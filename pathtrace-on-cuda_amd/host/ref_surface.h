@@ -95,7 +95,9 @@ public:
     // atomically (temporary name + rename) — point it at /dev/shm and a viewer can map the frame while the render goes on.
     std::string raw_path;
     // Tile split over several processes, one per GPU (new; the reference is single-device): this process renders tiles
-    // t % world == rank; the ranks meet through `id_file` (pt_comm_create_from_file) and rank 0 assembles and exports the frame.
+    // t % world == rank; the ranks meet through `id_file` (pt_comm_create_from_file_tagged: `job_tag` is any value the ranks of one
+    // job share and other jobs do not) and rank 0 assembles and exports the frame.  If any rank fails, every rank exits 99.
     int rank = 0, world = 1;
     std::string id_file;
+    unsigned long long job_tag = 0;
 };

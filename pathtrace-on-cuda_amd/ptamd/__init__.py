@@ -70,6 +70,7 @@ API = [
     ("pt_comm_unique_id", C.c_int, [_P]),
     ("pt_comm_create", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
     ("pt_comm_create_from_file", C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    ("pt_comm_create_from_file_tagged", C.c_int, [C.c_char_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
     ("pt_comm_destroy", None, [_P]),
     ("pt_comm_rank", C.c_int32, [_P]),
     ("pt_comm_world", C.c_int32, [_P]),
@@ -97,6 +98,7 @@ API = [
     ("pt_set_mode", C.c_int, [_P, C.c_int32]),
     ("pt_enable_trace_timing", C.c_int, [_P, C.c_int32]),
     ("pt_trace_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    ("pt_shade_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     ("pt_last_iterations", C.c_int, [_P]),
     ("pt_set_drain_threshold", C.c_int, [_P, C.c_int32]),
     ("pt_set_shade_rounds", C.c_int, [_P, C.c_int32]),
@@ -294,6 +296,12 @@ class Scene:
         _check(lib().pt_trace_timing(self._h, C.byref(s), C.byref(n), C.byref(m)), "pt_trace_timing")
         return s.value, n.value, m.value
 
+    def shade_timing(self):
+        """(sum_ms, launches, max_ms) of the wf_shade launches of the last render (HIP events on the launch stream)."""
+        s, n, m = C.c_double(), C.c_int32(), C.c_double()
+        _check(lib().pt_shade_timing(self._h, C.byref(s), C.byref(n), C.byref(m)), "pt_shade_timing")
+        return s.value, n.value, m.value
+
     def set_drain_threshold(self, live_streams):
         _check(lib().pt_set_drain_threshold(self._h, live_streams), "pt_set_drain_threshold")
 
@@ -364,10 +372,10 @@ def untile(d_gathered_ptr, cam, world, d_frame_ptr, stream_ptr=0):
 class Comm:
     """PtComm: the C-ABI's communicator for the single gather (RCCL under it when world > 1)."""
 
-    def __init__(self, rank=0, world=1, device=0, unique_id=None, id_file=None, timeout_s=60):
+    def __init__(self, rank=0, world=1, device=0, unique_id=None, id_file=None, timeout_s=60, job_tag=0):
         self._h = C.c_void_p()
         if id_file is not None:
-            _check(lib().pt_comm_create_from_file(id_file.encode(), rank, world, device, timeout_s, C.byref(self._h)), "pt_comm_create_from_file")
+            _check(lib().pt_comm_create_from_file_tagged(id_file.encode(), job_tag, rank, world, device, timeout_s, C.byref(self._h)), "pt_comm_create_from_file_tagged")
         else:
             buf = (C.c_uint8 * 128)(*(unique_id or bytes(128)))
             _check(lib().pt_comm_create(buf, rank, world, device, C.byref(self._h)), "pt_comm_create")

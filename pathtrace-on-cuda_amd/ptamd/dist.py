@@ -52,14 +52,19 @@ def gather_tiles(local_tiles, rank, world, group=None):
 class TileRenderer:
     """Per-rank device buffers for a (camera, params) pair; reusable across steps."""
 
-    def __init__(self, scene: Scene, cam, prm, device):
+    def __init__(self, scene: Scene, cam, prm, device, work=None):
+        """work: an existing scratch tensor to share (renders that run one after the other can use the same one); it must hold
+        at least pt_work_bytes() of this (camera, params) pair."""
         import torch
         self.torch = torch
         self.scene, self.cam, self.prm = scene, cam, prm
         self.device = device
         self.n_floats = tiles_floats(cam, prm)
         self.tiles = torch.empty(self.n_floats, dtype=torch.float32, device=device)
-        self.work = torch.empty(work_bytes(cam, prm) // 4, dtype=torch.float32, device=device)
+        need = work_bytes(cam, prm) // 4
+        if work is not None and work.numel() < need:
+            raise ValueError("shared work buffer too small: %d < %d floats" % (work.numel(), need))
+        self.work = work if work is not None else torch.empty(need, dtype=torch.float32, device=device)
 
     def render(self):
         """Enqueued on torch's current stream.  Blocks the calling thread until the render has drained in the default
