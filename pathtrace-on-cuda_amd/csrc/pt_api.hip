@@ -34,7 +34,7 @@ int ptk_wf_cohorts(size_t nUnits);
 const float* ptk_wf_staging(void* work);
 int ptk_wf_stack_capacity(void);
 hipError_t ptk_wf_render(int, const ptd::DevScene*, const ptd::DevCamera*, const ptd::DevParams*, void*, int, uint32_t*, hipStream_t, hipStream_t*,
-                         hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t*, int*, hipEvent_t*, int, int*, int, int, void*);
+                         hipEvent_t, hipEvent_t, hipEvent_t, hipEvent_t*, int*, hipEvent_t*, int, int*, int, int, void*, int);
 }
 
 void pt_set_error(const char* fmt, ...);   // pt_host.cpp
@@ -55,7 +55,7 @@ struct PtScene {
     ptd::DevScene dev{};
     void* d_nodes = nullptr; void* d_quad = nullptr; void* d_tri = nullptr; void* d_tripair = nullptr; void* d_leafbox = nullptr;
     void* d_surf = nullptr;
-    void* d_lights = nullptr; void* d_spheres = nullptr; void* d_lobe = nullptr;
+    void* d_lights = nullptr; void* d_spheres = nullptr;
     unsigned int* d_unit_counter = nullptr;
     void* d_counters = nullptr;
     int64_t bytes = 0;
@@ -67,6 +67,7 @@ struct PtScene {
     uint32_t* h_poll = nullptr;   // pinned, for the pipeline's live-stream count
     int last_iters = 0;
     int shade_rounds = 1;        // wf_shade: 1 = a stream may start its next sample in the step its path ends, 0 = one bounce per step, -1 = by live-stream count (PTAMD_TRS)
+    int early_below = 0;         // wf_shade starts beside the draining wf_trace once at most this many streams are alive (0 = never; pt_set_early_shade)
     int drain_below = 0;         // hand the last streams to wf_drain once this few are live (0 = never; measured slower than the tail it replaces)
     // optional per-launch timing of the traversal kernel (pt_enable_trace_timing)
     std::vector<hipEvent_t> trace_ev;
@@ -206,14 +207,6 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     auto okE = [](const float* e) { return std::isfinite(e[0]) && std::isfinite(e[1]) && std::isfinite(e[2]) && e[0] >= 0.f && e[1] >= 0.f && e[2] >= 0.f; };
     for (int i = 0; i < n_tris; i++) emitOk = emitOk && okE(tris[i].mat0.emittance);
     for (int i = 0; i < n_spheres; i++) emitOk = emitOk && okE(spheres[i].mat.emittance);
-    // lobe per primitive (the branch of include/CudaUtil.cuh:247-270 as pt_bxdf.h: lobe_of takes it): a scheduling hint for wf_shade
-    std::vector<uint8_t> lobe((size_t)n_tris + (size_t)n_spheres);
-    auto lobeOf = [](const PtMaterial& m) -> uint8_t {
-        if (m.opacity < (1.f - 0.0001f)) return (m.roughness < 1e-2f) ? 3 : 2;
-        return (m.roughness < 1e-2f) ? 1 : 0;
-    };
-    for (int i = 0; i < n_tris; i++) lobe[(size_t)i] = lobeOf(tris[i].mat0);
-    for (int i = 0; i < n_spheres; i++) lobe[(size_t)n_tris + (size_t)i] = lobeOf(spheres[i].mat);
     std::vector<float> sph((size_t)n_spheres * 16);
     for (int i = 0; i < n_spheres; i++) {
         const PtSphere& s = spheres[i];
@@ -235,8 +228,7 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
         (rc = upload(&sc->d_leafbox, accel.leafbox.data(), accel.leafbox.size() * 4, sc->bytes)) ||
         (rc = upload(&sc->d_surf, surf.data(), surf.size() * 4, sc->bytes)) ||
         (rc = upload(&sc->d_lights, lights.data(), lights.size() * 4, sc->bytes)) ||
-        (rc = upload(&sc->d_spheres, sph.data(), sph.size() * 4, sc->bytes)) ||
-        (rc = upload(&sc->d_lobe, lobe.data(), lobe.size(), sc->bytes))) {
+        (rc = upload(&sc->d_spheres, sph.data(), sph.size() * 4, sc->bytes))) {
         pt_scene_destroy(sc);
         return rc;
     }
@@ -258,6 +250,7 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     // environment overrides of the per-scene defaults (the same settings have C-ABI setters: pt_set_mode, pt_set_drain_threshold)
     if (const char* m = getenv("PTAMD_MODE")) { const int v = atoi(m); if (v >= 0 && v <= 1) sc->mode = v; }
     if (const char* m = getenv("PTAMD_DRAIN")) sc->drain_below = atoi(m);
+    if (const char* m = getenv("PTAMD_EARLY")) sc->early_below = atoi(m) > 0 ? atoi(m) : 0;
     // shading schedule (pt_set_shade_rounds): one bounce per step pays when wf_shade is bound by its arithmetic rather than by the
     // stream state it moves — measured: scenes whose surface table stays in L2 (+10 % on the Cornell room, 34 triangles) while
     // millions of streams are alive; with the 69,564-triangle bunny it is neutral, and with few streams in flight it loses
@@ -268,7 +261,6 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     sc->dev.leafbox = (const float4*)sc->d_leafbox; sc->dev.surf = (const float4*)sc->d_surf;
     sc->dev.lights = (const float4*)sc->d_lights; sc->dev.spheres = (const float4*)sc->d_spheres;
     sc->dev.n_quad = accel.n_quad;
-    sc->dev.lobe = (const uint8_t*)sc->d_lobe;
     sc->dev.nee_prune = (emitOk && !(getenv("PTAMD_PRUNE") && atoi(getenv("PTAMD_PRUNE")) == 0)) ? 1 : 0;      // PTAMD_PRUNE=0: A/B only
     sc->dev.n_nodes = n_wide; sc->dev.n_tris = n_tris; sc->dev.n_lights = n_lights; sc->dev.n_spheres = n_spheres;
     *out = sc;
@@ -279,7 +271,7 @@ void pt_scene_destroy(PtScene* s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* p[] = {s->d_nodes, s->d_quad, s->d_tri, s->d_tripair, s->d_leafbox, s->d_surf, s->d_lights, s->d_spheres, s->d_lobe, s->d_unit_counter, s->d_counters};
+    void* p[] = {s->d_nodes, s->d_quad, s->d_tri, s->d_tripair, s->d_leafbox, s->d_surf, s->d_lights, s->d_spheres, s->d_unit_counter, s->d_counters};
     for (void* q : p) if (q) (void)hipFree(q);
     for (int i = 0; i < PtScene::kEvRing; i++) for (int j = 0; j < 2; j++) if (s->ev[i][j]) (void)hipEventDestroy(s->ev[i][j]);
     if (s->h_poll) (void)hipHostFree(s->h_poll);
@@ -381,7 +373,7 @@ int pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm, float*
         HIPCHK(ptk_wf_render(s->device, &s->dev, &c, &d, d_work, kTraceBlocks, s->h_poll, stream, s->xstreams,
                              s->ev[slot][0], s->ev[slot][1], s->ev_fork, s->ev_join, &iters,
                              s->trace_ev.empty() ? nullptr : s->trace_ev.data(), (int)s->trace_ev.size() / 3, s->trace_ev_used, s->drain_below, s->shade_rounds,
-                             kTraceStat ? s->d_counters : nullptr));
+                             kTraceStat ? s->d_counters : nullptr, s->early_below));
         s->last_iters = iters;
         s->ev_count++;
         HIPCHK(ptk_sum_passes(ptk_wf_staging(d_work), d.passes, perPass, d_tiles, stream));
@@ -506,6 +498,12 @@ PT_API int pt_set_drain_threshold(PtScene* s, int32_t live_streams)
 {
     if (!s || live_streams < 0) { pt_set_error("pt_set_drain_threshold: bad argument"); return PT_ERR_INVALID; }
     s->drain_below = live_streams;
+    return PT_OK;
+}
+PT_API int pt_set_early_shade(PtScene* s, int32_t live_streams)
+{
+    if (!s || live_streams < 0) { pt_set_error("pt_set_early_shade: bad argument"); return PT_ERR_INVALID; }
+    s->early_below = live_streams;
     return PT_OK;
 }
 PT_API int pt_set_shade_rounds(PtScene* s, int32_t mode)

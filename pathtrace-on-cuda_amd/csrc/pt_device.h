@@ -60,7 +60,6 @@ struct DevScene {
     int32_t n_nodes, n_tris, n_lights, n_spheres;
     int32_t nee_prune;        // 1: every emittance in the scene is finite and >= 0, so dead NEE terms need no shadow ray (pt_stream.h: bounce)
     int32_t n_quad;           // records in `quad`; the first min(n_quad, 1024) are numbered breadth-first
-    const uint8_t* lobe;      // scattering lobe (pt_bxdf.h: Lobe) per primitive, triangles then spheres: scheduling hint only (wf_shade's lane sort)
 };
 
 struct DevCamera {

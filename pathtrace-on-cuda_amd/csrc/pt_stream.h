@@ -19,6 +19,7 @@ enum : uint32_t {
     F_CUR = 128,      // a current sample exists (started, not yet added to the pixel)
 };
 constexpr uint32_t kResumeBit = 0x80000000u;      // in a ray-queue entry: the stream's ray of that kind is a suspended traversal to resume
+constexpr int kNotReady = (int)0x80000000;      // hit.prim of a ray that has been emitted but not traced yet (set when a shade launch runs with MARK)
 constexpr int kRayKinds = 3;     // 0 path, 1 shadow of the current sample, 2 shadow of the older closed sample
 
 // Shadow rays only decide whether the closest hit is the sampled light point (GetLightColor, CudaUtil.cuh:150-166: visible iff
@@ -65,6 +66,7 @@ struct WfBuf {
     int* ovf;            // traversal stack overflow (entries >= kWfLdsStack), [level][thread]
     int* susp[2];        // suspended traversals (ping-pong by iteration): [record][kSuspInts]
     uint32_t suspCap;    // records per pool
+    uint8_t* res;        // per live-list position: what wf_shade's early phase did with the stream (R_* bits)
 };
 
 // StartRender prologue for one pixel & pass (srcs/pathtracer.cu:70-74): seeds the RNG, draws the
@@ -84,7 +86,8 @@ PT_DEV void init_stream(const DevCamera& cam, const DevParams& prm, const WfBuf&
     b.dir0[slot] = make_float4(d0.x, d0.y, d0.z, 0.f);
     b.ray_o[0][slot] = make_float4(cam.pos[0], cam.pos[1], cam.pos[2], 999999.f);
     b.ray_d[0][slot] = make_float4(d0.x, d0.y, d0.z, -__builtin_inff());
-    for (int k = 0; k < kRayKinds; k++) b.hit[k][slot] = make_float2(0.f, __int_as_float(-1));
+    b.hit[0][slot] = make_float2(0.f, __int_as_float(kNotReady));      // the camera ray: emitted, not traced yet
+    for (int k = 1; k < kRayKinds; k++) b.hit[k][slot] = make_float2(0.f, __int_as_float(-1));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -126,7 +129,6 @@ struct SState {
 // cosA / denom until the shadow ray is back), the BSDF sample and the roulette.  Leaves the shadow ray in st.sh* and,
 // unless the path ends here (returns true), the next path ray in st.pathO / pathD.
 // ---------------------------------------------------------------------------------------
-template <int LOBE = -1>      // LOBE >= 0: the caller knows the hit's lobe (lobe-sorted launches, wf_bounce); -1: read it from the material
 PT_DEV bool bounce(const DevScene& sc, const DevParams& prm, int prim, float t, const f3& rorg, const f3& rdir,
                    SState& st, bool& bRefracted, bool& neeOk, bool& needShadow)
 {
@@ -135,7 +137,7 @@ PT_DEV bool bounce(const DevScene& sc, const DevParams& prm, int prim, float t, 
     else surf_sphere(sc, prim - sc.n_tris, t, rorg, rdir, s);
     if (sqlen(s.m.emittance) > kEps) st.radiance += st.weight * s.m.emittance;   // :220-224
     const float ior = ior_of(s.m);                                          // :231
-    const int lobe = LOBE >= 0 ? LOBE : lobe_of(s.m);
+    const int lobe = lobe_of(s.m);
     const f3 wo = -rdir;
     // NEE sample (:235-245, SamplePrimitive :38-48)
     const NeeSample ns = nee_sample(sc, st.rng, s.p);
@@ -195,7 +197,7 @@ PT_DEV bool bounce(const DevScene& sc, const DevParams& prm, int prim, float t, 
 
 // Returns true when the stream has added its last sample to the pixel.  On return st.flags
 // describes the rays to trace next and the ray fields hold them.
-template <bool TWO, int LOBE = -1>
+template <bool TWO>
 PT_DEV bool shade_step_t(const DevScene& sc, const DevCamera& cam, const DevParams& prm, const WfBuf& b, uint32_t sid, SState& st,
                          float2 hitP, float2 hitS, float2 hitA)
 {
@@ -280,7 +282,7 @@ PT_DEV bool shade_step_t(const DevScene& sc, const DevCamera& cam, const DevPara
         }
         if (go) {
             bool needSh;
-            const bool terminate = bounce<LOBE>(sc, prm, prim, t, rorg, rdir, st, bRefracted, neeCur, needSh);
+            const bool terminate = bounce(sc, prm, prim, t, rorg, rdir, st, bRefracted, neeCur, needSh);
             shCur = needSh;
             if (!terminate) { pathCur = true; closing = false; }
             else {
@@ -338,7 +340,7 @@ PT_DEV bool shade_step_t(const DevScene& sc, const DevCamera& cam, const DevPara
         }
         if (go) {
             bool needSh;
-            const bool terminate = bounce<LOBE>(sc, prm, prim, t, rorg, rdir, st, bRefracted, neeCur, needSh);
+            const bool terminate = bounce(sc, prm, prim, t, rorg, rdir, st, bRefracted, neeCur, needSh);
             shCur = needSh;
             if (!terminate) { pathCur = true; closing = false; }
             else {

@@ -62,6 +62,10 @@ constexpr int kSuspInts = 4 + kWfLdsStack + kWfOvfLevels;
 // first kTopNodes nodes (breadth-first numbering, host/accel_build.cpp) are copied into LDS by every workgroup and
 // node steps on them read LDS instead.  80-byte stride: consecutive nodes start 20 banks apart, so the 16 lanes of
 // a ds_read_b128 group rarely collide.  Size: 16 KB of stacks + 6 KB of tree per workgroup, 7 workgroups per CU.
+// Node step: 1 = sort the four (entry distance, child) pairs (rounds 1-2), 0 = nearest child exactly, the others in slot order (round 3)
+#ifndef TRACE_SORT4
+#define TRACE_SORT4 1
+#endif
 #ifndef TRACE_TOP_NODES
 #define TRACE_TOP_NODES 0
 #endif
@@ -142,7 +146,7 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
 // closest one.
 // ---------------------------------------------------------------------------------------
 // STAT: a diagnostic build that also counts trips and the lanes they serve (pt_last_counters; PTAMD_TSTAT=1).
-template <int MODE>      // 0 production, 1 trip counters + histograms + timeline (PTAMD_TSTAT=1), 2 timeline only (PTAMD_TSTAT=2), 3 trip counters + section clocks, no per-step atomics (PTAMD_TSTAT=3)
+template <int MODE, bool PUBLISH = false>      // PUBLISH: hits are stored device-coherently (wf_shade PHASE 1 reads them while this kernel drains);  MODE: 0 production, 1 trip counters + histograms + timeline (PTAMD_TSTAT=1), 2 timeline only (PTAMD_TSTAT=2), 3 trip counters + section clocks, no per-step atomics (PTAMD_TSTAT=3)
 __global__ __launch_bounds__(256, TRACE_WAVES)
 void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift, int triTrig, int refillMin,
               int topWant, unsigned long long* stat, int statLaunch)
@@ -301,7 +305,8 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                         if (pend != 0) { if (sp < kWfLdsStack) stack[sp * 64] = pend; else ovf[(sp - kWfLdsStack) * ovfStride] = pend; sp++; pend = 0; }
                         r[0] = cur; r[1] = sp; r[2] = __float_as_int(bestT); r[3] = bestPrim;
                         for (int k = 0; k < sp; k++) r[4 + k] = (k < kWfLdsStack) ? stack[k * 64] : ovf[(k - kWfLdsStack) * ovfStride];
-                        b.hit[0][hs] = make_float2(bestT, __int_as_float(-2 - (int)rec));
+                        if (PUBLISH) __hip_atomic_store((unsigned long long*)&b.hit[0][hs], (unsigned long long)__float_as_uint(bestT) | ((unsigned long long)(uint32_t)(-2 - (int)rec) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else b.hit[0][hs] = make_float2(bestT, __int_as_float(-2 - (int)rec));
                         hasRay = false;
                         cur = kDone;
                     } else {
@@ -380,6 +385,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, cullT));
                     key[k] = (tn <= tf) ? __float_as_int(tn) : 0x7fffffff;   // tn >= 0: its bits order like ints
                 }
+#if TRACE_SORT4
                 // sort (entry distance, ref) pairs: 5 compare-exchanges, each one compare + four selects (equal distances: any order will do)
                 int k0 = key[0], k1 = key[1], k2 = key[2], k3 = key[3], r0 = (int)n1.x, r1 = (int)n1.y, r2 = (int)n1.z, r3 = (int)n1.w;
 #define PT_CE(ka, ra, kb, rb) { const bool sw = ka > kb; const int tk = sw ? kb : ka, tr = sw ? rb : ra; kb = sw ? ka : kb; rb = sw ? ra : rb; ka = tk; ra = tr; }
@@ -397,6 +403,27 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     sp--;
                     cur = stack_at(sp);
                 }
+#else
+                // The nearest hit child next, found exactly (a 4-way minimum of the entry distances and four equality tests: 9 slow-class
+                // instructions where sorting all four (distance, ref) pairs took 25); the other hit children go to the stack in slot order.
+                // Measured on the config scenes' ray mix (tools/quad_order_lab.cpp): +0 ... +1.2 % node steps against the full sort — what
+                // matters is which child is entered first, hardly in which order the others wait.  The closest hit does not depend on
+                // the order of tests (tie rule), so this is result-neutral.
+                const int kmin = min(min(key[0], key[1]), min(key[2], key[3]));
+                if (kmin != 0x7fffffff) {
+                    const bool m0 = key[0] == kmin, m1 = !m0 && key[1] == kmin, m2 = !m0 && !m1 && key[2] == kmin, m3 = !m0 && !m1 && !m2;
+                    if (key[3] != 0x7fffffff && !m3) { if (sp < kWfLdsStack) stack[sp * 64] = (int)n1.w; else ovf[(sp - kWfLdsStack) * ovfStride] = (int)n1.w; sp++; }
+                    if (key[2] != 0x7fffffff && !m2) { if (sp < kWfLdsStack) stack[sp * 64] = (int)n1.z; else ovf[(sp - kWfLdsStack) * ovfStride] = (int)n1.z; sp++; }
+                    if (key[1] != 0x7fffffff && !m1) { if (sp < kWfLdsStack) stack[sp * 64] = (int)n1.y; else ovf[(sp - kWfLdsStack) * ovfStride] = (int)n1.y; sp++; }
+                    if (key[0] != 0x7fffffff && !m0) { if (sp < kWfLdsStack) stack[sp * 64] = (int)n1.x; else ovf[(sp - kWfLdsStack) * ovfStride] = (int)n1.x; sp++; }
+                    cur = m0 ? (int)n1.x : (m1 ? (int)n1.y : (m2 ? (int)n1.z : (int)n1.w));
+                } else if (sp == 0) {
+                    cur = kDone;
+                } else {
+                    sp--;
+                    cur = stack_at(sp);
+                }
+#endif
                 if (HIST) atomicAdd(&stat[8 + 3 * 2700 + 32 + 2700 + 64 + (sp > 31 ? 31 : sp)], 1ull);      // stack depth after this node step
                 if (cur < 0 && cur != kDone && pend == 0) {
                     // park the leaf, carry on with the next stack entry
@@ -428,7 +455,8 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     float root;
                     if (sphere_root(f3(c.x, c.y, c.z), c.w, org, dir, bestT, root)) { bestT = root; bestPrim = sc.n_tris + s; }
                 }
-                b.hit[0][hs] = make_float2(bestT, __int_as_float(bestPrim));
+                if (PUBLISH) __hip_atomic_store((unsigned long long*)&b.hit[0][hs], (unsigned long long)__float_as_uint(bestT) | ((unsigned long long)(uint32_t)bestPrim << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else b.hit[0][hs] = make_float2(bestT, __int_as_float(bestPrim));
                 hasRay = false;
                 if (STAT) stRays++;
                 if (HIST) atomicAdd(&stat[8 + 3 * 2700 + 32 + 2700 + (steps >= 252 ? 63 : steps >> 2)], 1ull);      // node steps of this ray (this launch), bins of 4
@@ -461,76 +489,63 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
 // ---------------------------------------------------------------------------------------
 // wf_shade: one thread per live stream, one bounce.
 // ---------------------------------------------------------------------------------------
-// SORT (round 3): the streams of a workgroup are re-dealt to its lanes by the lobe of the bounce they are about to shade (the reference's
-// 4-way branch, CudaUtil.cuh:247-334), so that a wave runs one lobe's code instead of all of them under masks: a stable counting
-// sort of the workgroup's <= 1024 list entries through LDS (class = lobe 0..3 | 4 no bounce this step | 5 no stream), each lane then
-// shades the stream it was dealt, and the outcome goes back through LDS to the lane that owns the entry, which does the appends —
-// so every list keeps the order of the live list (stream order) exactly as without the sort.  The class only steers scheduling (it
-// comes from DevScene::lobe, a byte per primitive); the bounce itself still reads the lobe from the material.  Result-neutral.
-template <int WAVES, bool TWO, bool SORT = false>
+// PHASE (round 3, "early shade"): the launch tail of wf_trace — the last rays of a launch finishing in ever emptier waves — leaves the
+// chip idle for ~0.3 ms per iteration, which is most of an iteration for one rank of an 8-way tile split.  With PHASE 1 / 2 the shade
+// step of an iteration is cut in two launches:
+//   PHASE 1 (early)  runs on a second HIP stream BESIDE the draining wf_trace: its workgroups get wave slots as traversal waves leave.
+//                    A stream is shaded only if every ray it is waiting for is already back — wf_trace publishes a hit with a
+//                    device-scope store, the slot held kNotReady since the ray was emitted (MARK) and is read here with a device-scope
+//                    load (the XCDs' L2s are not coherent with each other) —, otherwise it is left alone.  Nothing is appended here: the
+//                    outcome of a shaded stream (alive / which rays it emitted) is parked in res[list position].  No waiting, no
+//                    spinning: a stream whose rays are not back is simply skipped.
+//   PHASE 2 (rest)   runs after both have finished: shades the streams phase 1 skipped and does ALL the appends, in list order — so the
+//                    live list and the ray queues keep stream order exactly as with one launch.
+// A stream goes through the same shade_step either way: result-neutral.
+enum : uint32_t { R_ALIVE = 1, R_EMIT0 = 2, R_EMIT1 = 4, R_EMIT2 = 8, R_RESUME = 16, R_DONE = 128 };
+
+PT_DEV float2 load_hit_coherent(const float2* p)
+{
+    const unsigned long long v = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32)));
+}
+
+template <int WAVES, bool TWO, int PHASE = 0, bool MARK = false>
 __global__ __launch_bounds__(WAVES * 256, WAVES)
 void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, int slotOut, int slotClear, int listIn)
 {
+    static_assert(PHASE == 0 || MARK, "the two-phase step needs the not-ready marks");
     const uint32_t nIn = b.cnt[slotIn].nActive;
-    if (blockIdx.x == 0) for (int k = threadIdx.x; k < kWfSlotBytes / 4; k += blockDim.x) ((uint32_t*)&b.cnt[slotClear])[k] = 0;
+    if (PHASE != 1 && blockIdx.x == 0) for (int k = threadIdx.x; k < kWfSlotBytes / 4; k += blockDim.x) ((uint32_t*)&b.cnt[slotClear])[k] = 0;
     if ((uint32_t)blockIdx.x * blockDim.x >= nIn) return;
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    bool have = idx < nIn;
+    const bool have = idx < nIn;
     bool alive = false, emit[kRayKinds] = {false, false, false};
     uint32_t sid = 0, resume = 0;      // resume: the queued rays are suspended traversals (wf_trace then reads their records)
-    uint32_t mySid = 0;                // SORT: the stream of this lane's own list entry (what it appends)
-    [[maybe_unused]] __shared__ uint32_t s_sid[SORT ? kShadeThreads : 1];
-    [[maybe_unused]] __shared__ uint16_t s_src[SORT ? kShadeThreads : 1];
-    [[maybe_unused]] __shared__ uint32_t s_res[SORT ? kShadeThreads : 1];
-    [[maybe_unused]] __shared__ uint32_t s_cls[SORT ? 6 * (kShadeThreads / 64) : 1];
-    [[maybe_unused]] uint32_t src = threadIdx.x;
-    if (have) sid = b.active[listIn][idx];
-    if constexpr (SORT) {
-        mySid = sid;
-        // ---- class of this entry's step: which lobe its bounce will run (pt_stream.h: shade_step_t decides the same way) ----
-        int cls = 5;
-        if (have) {
-            const uint4 r1 = b.rng1[sid];
-            const uint32_t fl = r1.w;
-            const float2 hP = b.hit[0][sid], hS = b.hit[1][sid], hA = b.hit[2][sid];
-            const int pP = (fl & F_PATH) ? __float_as_int(hP.y) : -1, pS = (fl & F_SHADOW) ? __float_as_int(hS.y) : -1, pA = (fl & F_SHADOWA) ? __float_as_int(hA.y) : -1;
-            cls = 4;
-            if (!(pP <= -2 || pS <= -2 || pA <= -2)) {
-                int prim = -1;
-                bool cur = (fl & F_CUR) != 0;
-                if (!(fl & F_PRIMARY) && !(fl & F_PATH) && cur) cur = false;
-                if ((fl & F_PATH) && !(fl & F_PRIMARY)) { prim = pP; if (prim < 0) cur = false; }
-                if (prim < 0 && !cur && (r1.z >> 16) > 0) prim = (fl & F_PRIMARY) ? pP : __float_as_int(b.hit0[sid].y);
-                if (prim >= 0) cls = sc.lobe[prim];
+    bool step = have;
+    if (have) {
+        sid = b.active[listIn][idx];
+        if (PHASE == 2) {
+            const uint32_t r = b.res[idx];
+            if (r & R_DONE) {      // shaded by phase 1: only the appends are left
+                step = false;
+                alive = (r & R_ALIVE) != 0; emit[0] = (r & R_EMIT0) != 0; emit[1] = (r & R_EMIT1) != 0; emit[2] = (r & R_EMIT2) != 0;
             }
         }
-        // ---- stable counting sort of the workgroup's entries by class ----
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
-        unsigned long long mine = 0;
-#pragma unroll
-        for (int c = 0; c < 6; c++) { const unsigned long long m = __ballot(cls == c); if (cls == c) mine = m; if (lane == 0) s_cls[c * (kShadeThreads / 64) + wave] = (uint32_t)__builtin_popcountll(m); }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t run = 0;
-            for (int c = 0; c < 6; c++) for (int w = 0; w < nw; w++) { const uint32_t v = s_cls[c * (kShadeThreads / 64) + w]; s_cls[c * (kShadeThreads / 64) + w] = run; run += v; }
-        }
-        __syncthreads();
-        const uint32_t pos = s_cls[cls * (kShadeThreads / 64) + wave] + (uint32_t)__builtin_popcountll(mine & ((1ull << lane) - 1ull));
-        s_sid[pos] = have ? sid : 0xffffffffu;
-        s_src[pos] = (uint16_t)threadIdx.x;
-        __syncthreads();
-        sid = s_sid[threadIdx.x]; src = s_src[threadIdx.x];
-        have = sid != 0xffffffffu;
-        if (!have) sid = 0;
     }
-    if (have) {
+    if (step) {
         SState st;
-        const float2 hitP = b.hit[0][sid], hitS = b.hit[1][sid], hitA = b.hit[2][sid];      // same fetch level as the state
+        float2 hitP, hitS, hitA;
+        if (PHASE == 1) { hitP = load_hit_coherent(&b.hit[0][sid]); hitS = load_hit_coherent(&b.hit[1][sid]); hitA = load_hit_coherent(&b.hit[2][sid]); }
+        else { hitP = b.hit[0][sid]; hitS = b.hit[1][sid]; hitA = b.hit[2][sid]; }      // same fetch level as the state
         load_state(b, sid, st);
         // a ray of this stream is still being traversed (time-sliced): wait one iteration
         const int pendP = (st.flags & F_PATH) ? __float_as_int(hitP.y) : -1, pendS = (st.flags & F_SHADOW) ? __float_as_int(hitS.y) : -1;
         const int pendA = (st.flags & F_SHADOWA) ? __float_as_int(hitA.y) : -1;
-        if (pendP <= -2 || pendS <= -2 || pendA <= -2) {
+        if (PHASE == 1 && (pendP <= -2 || pendS <= -2 || pendA <= -2)) {
+            // phase 1: a ray is not back yet (kNotReady), or a traversal is suspended (its slot keeps the record number until wf_trace
+            // resumes it, so the slot cannot tell "back" from "not yet"): phase 2 takes the stream
+            step = false;
+        } else if (pendP <= -2 || pendS <= -2 || pendA <= -2) {
             alive = true; emit[0] = pendP <= -2; emit[1] = pendS <= -2; emit[2] = pendA <= -2; resume = kResumeBit;
         } else {
             const bool done = shade_step_t<TWO>(sc, cam, prm, b, sid, st, hitP, hitS, hitA);
@@ -544,13 +559,15 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
             }
         }
     }
-    if constexpr (SORT) {
-        // the outcome goes back to the lane that owns the list entry
-        s_res[src] = (alive ? 1u : 0u) | (emit[0] ? 2u : 0u) | (emit[1] ? 4u : 0u) | (emit[2] ? 8u : 0u) | (resume ? 16u : 0u);
-        __syncthreads();
-        const uint32_t r = s_res[threadIdx.x];
-        alive = (r & 1u) != 0; emit[0] = (r & 2u) != 0; emit[1] = (r & 4u) != 0; emit[2] = (r & 8u) != 0; resume = (r & 16u) ? kResumeBit : 0u;
-        sid = mySid;
+    // MARK: the hit slot of every ray this step emitted says "not traced yet" until wf_trace publishes its hit (a suspended traversal
+    // that is re-queued keeps its slot: it holds the record number).  Written here, at the end, where nothing else is live.
+    if (MARK && step && !resume) {
+#pragma unroll
+        for (int k = 0; k < kRayKinds; k++) if (emit[k]) b.hit[k][sid] = make_float2(0.f, __int_as_float(kNotReady));
+    }
+    if (PHASE == 1) {
+        if (have) b.res[idx] = (uint8_t)(step ? (R_DONE | (alive ? R_ALIVE : 0u) | (emit[0] ? R_EMIT0 : 0u) | (emit[1] ? R_EMIT1 : 0u) | (emit[2] ? R_EMIT2 : 0u)) : 0u);
+        return;
     }
     const bool e[kLists] = {alive, emit[0], emit[1], emit[2]};
     uint32_t* const c[kLists] = {&b.cnt[slotOut].nActive, &b.cnt[slotOut].nRays[0][0], &b.cnt[slotOut].nRays[1][0], &b.cnt[slotOut].nRays[2][0]};
@@ -664,6 +681,7 @@ static size_t cohort_bytes(size_t nStreams, int traceBlocks)
     b += 3 * ptd::kWfSlotBytes; // counters
     b += (size_t)traceBlocks * 256 * ptd::kWfOvfLevels * 4;
     b += 2 * ((nStreams / 4 + 1024) * ptd::kSuspInts * 4 + 16);
+    b += n16 + 16;                            // res: one byte per live-list position (early shade)
     return b + 512;
 }
 static size_t staging_bytes(size_t nStreams) { return ((nStreams * 12 + 16) + 255) & ~(size_t)255; }
@@ -707,6 +725,7 @@ static void carve(char* p, size_t nStreams, int traceBlocks, ptd::WfBuf& b)
     b.ovf = (int*)take((size_t)traceBlocks * 256 * ptd::kWfOvfLevels * 4);
     b.suspCap = (uint32_t)(nStreams / 4 + 1024);
     for (int k = 0; k < 2; k++) b.susp[k] = (int*)take((size_t)b.suspCap * ptd::kSuspInts * 4);
+    b.res = (uint8_t*)take(n16);
 }
 
 const float* ptk_wf_staging(void* work) { return (const float*)work; }
@@ -715,7 +734,8 @@ const float* ptk_wf_staging(void* work) { return (const float*)work; }
 // drained (it polls the live-stream count every 16..64 iterations).
 static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::DevCamera* cam, ptd::DevParams prm,
                              ptd::WfBuf b, int traceBlocks, uint32_t* h_cnt, hipStream_t stream,
-                             hipEvent_t* trace_ev, int trace_ev_pairs, int* trace_ev_used, int drainBelow, int shadeRounds, int* iters_out, unsigned long long* traceStat)
+                             hipEvent_t* trace_ev, int trace_ev_pairs, int* trace_ev_used, int drainBelow, int shadeRounds, int* iters_out, unsigned long long* traceStat,
+                             hipStream_t aux, hipEvent_t* evOvl, int earlyBelow)
 {
     using namespace ptd;
     hipError_t e;
@@ -742,7 +762,6 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     // two per CU; other shapes re-measured after that change: 256 threads -4 %, 384 / 768 -13 %, 1024 -8 %, 3 waves/SIMD -9...-13 %
     // (profiles/r02_experiments/r02_t16_shade_shapes_after_noslp.log)
     static const int shadeThreads = (getenv("PTAMD_ST") && atoi(getenv("PTAMD_ST")) >= 64 && atoi(getenv("PTAMD_ST")) <= kShadeThreads) ? (atoi(getenv("PTAMD_ST")) & ~63) : 512;
-    static const bool shadeSort = getenv("PTAMD_SORT") && atoi(getenv("PTAMD_SORT")) != 0;      // wf_shade: lanes re-dealt by lobe inside a workgroup
     static const int refillMin = getenv("PTAMD_RF") ? atoi(getenv("PTAMD_RF")) : kWfRefill;     // idle lanes that trigger a refill
     static const int triTrig = getenv("PTAMD_TT") ? atoi(getenv("PTAMD_TT")) : 64;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
@@ -764,17 +783,34 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
             const bool timed = trace_ev && it < trace_ev_pairs;
             if (timed) (void)hipEventRecord(trace_ev[3 * it], stream);
+            // early shade (wf_shade PHASE 1 / 2): once few enough streams are alive that the traversal's launch tail is a large part
+            // of an iteration, the shade step starts on `aux` beside the draining wf_trace and the rest follows both (result-neutral).
+            // `marks`: every shade launch of this render sets the not-ready marks, so that the switch can happen at any iteration.
+            const bool marks = aux != nullptr && earlyBelow > 0;
+            const bool early = marks && !traceStat && liveBound <= (uint32_t)earlyBelow;
+            if (early) {
+                // aux may start once the previous iteration's shade (everything on `stream` so far) is done
+                if ((e = hipEventRecord(evOvl[it & 1], stream)) != hipSuccess) return e;
+                if ((e = hipStreamWaitEvent(aux, evOvl[it & 1], 0)) != hipSuccess) return e;
+            }
             if (traceStat && traceStatClk) hipLaunchKernelGGL(wf_trace<3>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
             else if (traceStat && traceStatFull) hipLaunchKernelGGL(wf_trace<1>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
             else if (traceStat) hipLaunchKernelGGL(wf_trace<2>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
+            else if (early) hipLaunchKernelGGL((wf_trace<0, true>), dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, 0);
             else hipLaunchKernelGGL(wf_trace<0>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, 0);
             if (timed) (void)hipEventRecord(trace_ev[3 * it + 1], stream);
             const dim3 sg((liveBound + shadeThreads - 1) / shadeThreads), sb(shadeThreads);
             const bool twoRounds = shadeRounds >= 0 ? (shadeRounds != 0) : (liveBound < trStreams);
-#define PT_SHADE(W, T, S) hipLaunchKernelGGL((wf_shade<W, T, S>), sg, sb, 0, stream, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1)
-            if (shadeSort) { if (twoRounds) PT_SHADE(4, true, true); else PT_SHADE(4, false, true); }
-            else if (twoRounds) { if (shadeWaves == 2) PT_SHADE(2, true, false); else if (shadeWaves == 3) PT_SHADE(3, true, false); else PT_SHADE(4, true, false); }
-            else { if (shadeWaves == 2) PT_SHADE(2, false, false); else if (shadeWaves == 3) PT_SHADE(3, false, false); else PT_SHADE(4, false, false); }
+#define PT_SHADE(W, T, P, M, S) hipLaunchKernelGGL((wf_shade<W, T, P, M>), sg, sb, 0, S, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1)
+            if (early) {
+                if (twoRounds) PT_SHADE(4, true, 1, true, aux); else PT_SHADE(4, false, 1, true, aux);
+                if ((e = hipEventRecord(evOvl[2 + (it & 1)], aux)) != hipSuccess) return e;
+                if ((e = hipStreamWaitEvent(stream, evOvl[2 + (it & 1)], 0)) != hipSuccess) return e;
+                if (twoRounds) PT_SHADE(4, true, 2, true, stream); else PT_SHADE(4, false, 2, true, stream);
+            }
+            else if (marks) { if (twoRounds) PT_SHADE(4, true, 0, true, stream); else PT_SHADE(4, false, 0, true, stream); }
+            else if (twoRounds) { if (shadeWaves == 2) PT_SHADE(2, true, 0, false, stream); else if (shadeWaves == 3) PT_SHADE(3, true, 0, false, stream); else PT_SHADE(4, true, 0, false, stream); }
+            else { if (shadeWaves == 2) PT_SHADE(2, false, 0, false, stream); else if (shadeWaves == 3) PT_SHADE(3, false, 0, false, stream); else PT_SHADE(4, false, 0, false, stream); }
 #undef PT_SHADE
             if (timed) (void)hipEventRecord(trace_ev[3 * it + 2], stream);      // [3it+1, 3it+2] brackets this iteration's wf_shade
         }
@@ -807,7 +843,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
 hipError_t ptk_wf_render(int device, const ptd::DevScene* sc, const ptd::DevCamera* cam, const ptd::DevParams* prm,
                          void* work, int traceBlocks, uint32_t* h_cnt, hipStream_t stream, hipStream_t* xstreams,
                          hipEvent_t ev_begin, hipEvent_t ev_end, hipEvent_t ev_fork, hipEvent_t* ev_join, int* iters_out,
-                         hipEvent_t* trace_ev, int trace_ev_pairs, int* trace_ev_used, int drainBelow, int shadeRounds, void* traceStat)
+                         hipEvent_t* trace_ev, int trace_ev_pairs, int* trace_ev_used, int drainBelow, int shadeRounds, void* traceStat, int earlyBelow)
 {
     using namespace ptd;
     const size_t nUnits = (size_t)prm->n_units;
@@ -834,7 +870,12 @@ hipError_t ptk_wf_render(int device, const ptd::DevScene* sc, const ptd::DevCame
         hipEvent_t* tev = trace_ev ? trace_ev + (size_t)3 * evPer * c : nullptr;
         int* used = trace_ev_used ? &trace_ev_used[c] : nullptr;
         if (cp.n_units == 0) { if (used) *used = 0; continue; }
-        auto job = [=, &rc, &iters]() { rc[(size_t)c] = run_cohort(device, sc, cam, cp, b, traceBlocks, h_cnt + 16 * c, cs, tev, evPer, used, drainBelow, shadeRounds, &iters[(size_t)c], (unsigned long long*)traceStat); };
+        // early shade needs a second stream and four events: with one cohort the scene's extra streams and fork / join events are free
+        hipStream_t aux = (C == 1) ? xstreams[0] : nullptr;
+        auto job = [=, &rc, &iters]() {
+            hipEvent_t evOvl[4] = {ev_fork, ev_join[0], ev_join[1], ev_join[2]};
+            rc[(size_t)c] = run_cohort(device, sc, cam, cp, b, traceBlocks, h_cnt + 16 * c, cs, tev, evPer, used, drainBelow, shadeRounds, &iters[(size_t)c], (unsigned long long*)traceStat, aux, evOvl, earlyBelow);
+        };
         if (C == 1) job(); else th.emplace_back(job);
     }
     for (auto& t : th) t.join();

@@ -102,6 +102,7 @@ API = [
     ("pt_last_iterations", C.c_int, [_P]),
     ("pt_set_drain_threshold", C.c_int, [_P, C.c_int32]),
     ("pt_set_shade_rounds", C.c_int, [_P, C.c_int32]),
+    ("pt_set_early_shade", C.c_int, [_P, C.c_int32]),
 ]
 
 
@@ -304,6 +305,10 @@ class Scene:
 
     def set_drain_threshold(self, live_streams):
         _check(lib().pt_set_drain_threshold(self._h, live_streams), "pt_set_drain_threshold")
+
+    def set_early_shade(self, live_streams):
+        """wf_shade starts beside the draining wf_trace while at most this many streams are alive (0 = never).  Result-neutral."""
+        _check(lib().pt_set_early_shade(self._h, live_streams), "pt_set_early_shade")
 
     def set_shade_rounds(self, mode):
         """1: next sample starts in the step a path ends; 0: one bounce per step; -1: by live-stream count (result-neutral)."""

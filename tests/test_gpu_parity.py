@@ -341,6 +341,38 @@ def test_shading_schedule_switches_inside_a_render():
     assert np.array_equal(bits(frames[0]), bits(frames[1])) and np.array_equal(bits(frames[0]), bits(frames[2]))
 
 
+def test_early_shade_is_result_neutral():
+    """pt_set_early_shade: the shade step starts on a second stream beside the draining traversal kernel (streams whose rays are all back),
+    the rest follows.  Same bits as the one-launch step — always on, switched on part-way through a render as streams retire, with
+    both shading schedules, with spheres (all four lobes) and time-sliced rays — and the same bits as the oracle's golden image."""
+    prims = ptamd.gen_scene(1, 24)
+    nodes, tris, _ = ptamd.build_bvh(prims)
+    sph = make_test_spheres()
+    sc = ptamd.Scene(nodes, tris, sph)
+    cam = ptamd.make_camera(160, 90)
+    prm = ptamd.default_params(passes=2, spp_per_pass=6)
+    sc.set_early_shade(0)
+    base = sc.render(cam, prm)
+    assert np.isfinite(base).all() and base.mean() > 0.05
+    for rounds in (1, 0):
+        sc.set_shade_rounds(rounds)
+        for below in (1 << 30, 9000, 1):      # always / from the point where 9,000 of the 28,800 streams are left / only for the very last stream
+            sc.set_early_shade(below)
+            assert np.array_equal(bits(sc.render(cam, prm)), bits(base)), (rounds, below)
+    # a larger frame: a window of 1080p rendered as one rank of an 8-way split (the size the feature is for) against the plain step
+    big = ptamd.Scene.from_prims(ptamd.gen_scene(1, 187))
+    cam = ptamd.make_camera(1920, 1080)
+    import torch
+    from ptamd.dist import TileRenderer
+    out = []
+    for below in (0, 1 << 30):
+        big.set_early_shade(below)
+        tr = TileRenderer(big, cam, ptamd.default_params(passes=2, spp_per_pass=4, rank=3, world=8), torch.device("cuda:0"))
+        out.append(tr.render().cpu().numpy().copy())
+    assert np.isfinite(out[0]).all() and out[0].mean() > 0.05
+    assert np.array_equal(bits(out[0]), bits(out[1]))
+
+
 def test_error_paths():
     prims = ptamd.gen_scene(0)
     nodes, tris, _ = ptamd.build_bvh(prims[:10])               # drop the light quad -> no emissive triangle
