@@ -299,12 +299,13 @@ PT_API int  pt_last_iterations(PtScene* s);
  * most `live_streams` are still alive (0 = never, the default: on MI355X the drain launch measured
  * slower than the latency-bound iterations it replaces).  Result-neutral. */
 PT_API int  pt_set_drain_threshold(PtScene* s, int32_t live_streams);
-/* Mode 1, early shade: while at most `live_streams` streams are alive, the shade step of an iteration starts on a second HIP stream
- * beside the draining traversal kernel (streams whose rays are all back are shaded at once, the others — and all list appends —
- * follow when the traversal has finished); 0 = never.  The traversal's launch tail (~0.3 ms whatever the launch size) is most of an
- * iteration for one rank of an 8-way tile split.  Result-neutral: every stream goes through the same step
- * (pathtrace-on-cuda_amd/csrc/pt_wavefront.hip: wf_shade PHASE 1 / 2).  Environment PTAMD_EARLY overrides the default. */
-PT_API int  pt_set_early_shade(PtScene* s, int32_t live_streams);
+/* Mode 1, early shade: in a render call of at most `max_streams` streams (pixels of this rank x passes of the call) the shade step of
+ * every iteration starts on a second HIP stream beside the draining traversal kernel (streams whose rays are all back are shaded at
+ * once, the others — and all list appends — follow when the traversal has finished); 0 = never, default 2,500,000: on for one rank of
+ * an 8-way tile split of 1080p x 8 passes (-6.5 % time), off for a full frame (whose launches are large next to the traversal's
+ * ~0.3 ms launch tail).  Result-neutral: every stream goes through the same step (pathtrace-on-cuda_amd/csrc/pt_wavefront.hip:
+ * wf_shade PHASE 1 / 2).  Environment PTAMD_EARLY overrides the default. */
+PT_API int  pt_set_early_shade(PtScene* s, int32_t max_streams);
 /* Mode 1, shading schedule: 1 = a stream whose path ends starts its next sample in the same step (bounces - 1 steps per sample,
  * two bounce evaluations per step), 0 = one bounce evaluation per step (bounces steps per sample, a shorter step), -1 = 0 while
  * more than PTAMD_TRS (4 M) streams are alive, 1 below.  Default: -1 for scenes whose surface table fits in L2 (<= 2 MB: +10 % on

@@ -67,7 +67,7 @@ struct PtScene {
     uint32_t* h_poll = nullptr;   // pinned, for the pipeline's live-stream count
     int last_iters = 0;
     int shade_rounds = 1;        // wf_shade: 1 = a stream may start its next sample in the step its path ends, 0 = one bounce per step, -1 = by live-stream count (PTAMD_TRS)
-    int early_below = 0;         // wf_shade starts beside the draining wf_trace once at most this many streams are alive (0 = never; pt_set_early_shade)
+    int early_below = 2500000;   // renders of at most this many streams (pixels x passes of one call) run wf_shade's early phase beside the draining wf_trace (0 = never; pt_set_early_shade)
     int drain_below = 0;         // hand the last streams to wf_drain once this few are live (0 = never; measured slower than the tail it replaces)
     // optional per-launch timing of the traversal kernel (pt_enable_trace_timing)
     std::vector<hipEvent_t> trace_ev;
@@ -202,9 +202,13 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
             n_lights++;
         }
     }
-    // dead-NEE-term pruning (pt_stream.h: bounce) needs every emittance a shadow ray can return to be finite and non-negative
+    // dead-NEE-term pruning (pt_stream.h: bounce) needs every emittance a shadow ray can return to be finite, non-negative and small
+    // enough that (weight * brdfcos) * Le cannot overflow where the pruned case assumes it is finite: |wb| < 1e30 and Le <= 1e8 give
+    // |wb * Le| < 1e38 < FLT_MAX.  (With a brighter light wb * Le can be inf, inf * 0 is NaN, and the reference adds that NaN to the
+    // radiance, include/CudaUtil.cuh:271-272; such scenes keep all their shadow rays.)
     bool emitOk = true;
-    auto okE = [](const float* e) { return std::isfinite(e[0]) && std::isfinite(e[1]) && std::isfinite(e[2]) && e[0] >= 0.f && e[1] >= 0.f && e[2] >= 0.f; };
+    auto okE = [](const float* e) { return std::isfinite(e[0]) && std::isfinite(e[1]) && std::isfinite(e[2]) && e[0] >= 0.f && e[1] >= 0.f && e[2] >= 0.f &&
+                                           e[0] <= 1e8f && e[1] <= 1e8f && e[2] <= 1e8f; };
     for (int i = 0; i < n_tris; i++) emitOk = emitOk && okE(tris[i].mat0.emittance);
     for (int i = 0; i < n_spheres; i++) emitOk = emitOk && okE(spheres[i].mat.emittance);
     std::vector<float> sph((size_t)n_spheres * 16);
@@ -250,7 +254,7 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     // environment overrides of the per-scene defaults (the same settings have C-ABI setters: pt_set_mode, pt_set_drain_threshold)
     if (const char* m = getenv("PTAMD_MODE")) { const int v = atoi(m); if (v >= 0 && v <= 1) sc->mode = v; }
     if (const char* m = getenv("PTAMD_DRAIN")) sc->drain_below = atoi(m);
-    if (const char* m = getenv("PTAMD_EARLY")) sc->early_below = atoi(m) > 0 ? atoi(m) : 0;
+    if (const char* m = getenv("PTAMD_EARLY")) sc->early_below = atoi(m) > 0 ? atoi(m) : 0;      // 0 = off
     // shading schedule (pt_set_shade_rounds): one bounce per step pays when wf_shade is bound by its arithmetic rather than by the
     // stream state it moves — measured: scenes whose surface table stays in L2 (+10 % on the Cornell room, 34 triangles) while
     // millions of streams are alive; with the 69,564-triangle bunny it is neutral, and with few streams in flight it loses

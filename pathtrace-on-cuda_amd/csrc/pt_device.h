@@ -58,7 +58,7 @@ struct DevScene {
     const float4* lights;
     const float4* spheres;
     int32_t n_nodes, n_tris, n_lights, n_spheres;
-    int32_t nee_prune;        // 1: every emittance in the scene is finite and >= 0, so dead NEE terms need no shadow ray (pt_stream.h: bounce)
+    int32_t nee_prune;        // 1: every emittance in the scene is finite, >= 0 and <= 1e8, so dead NEE terms need no shadow ray (pt_stream.h: bounce)
     int32_t n_quad;           // records in `quad`; the first min(n_quad, 1024) are numbered breadth-first
 };
 

@@ -8,6 +8,86 @@
 
 namespace ptd {
 
+// Stream state, rays and hit records are touched once per kernel by one lane each: PT_STREAM_NT = 1 moves them with non-temporal
+// loads / stores (the `nt` cache hint) so that they do not push the traversal tree and the surface table out of the L2s.
+#ifndef PT_STREAM_NT
+#define PT_STREAM_NT 0
+#endif
+#ifndef PT_STREAM_NT_LD
+#define PT_STREAM_NT_LD PT_STREAM_NT
+#endif
+#ifndef PT_STREAM_NT_ST
+#define PT_STREAM_NT_ST PT_STREAM_NT
+#endif
+typedef float pt_v4f __attribute__((ext_vector_type(4)));
+typedef float pt_v2f __attribute__((ext_vector_type(2)));
+typedef uint32_t pt_v4u __attribute__((ext_vector_type(4)));
+PT_DEV float4 ld_s(const float4* p) {
+#if PT_STREAM_NT_LD
+    const pt_v4f v = __builtin_nontemporal_load((const pt_v4f*)p); return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+PT_DEV uint4 ld_s(const uint4* p) {
+#if PT_STREAM_NT_LD
+    const pt_v4u v = __builtin_nontemporal_load((const pt_v4u*)p); return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+PT_DEV float2 ld_s(const float2* p) {
+#if PT_STREAM_NT_LD
+    const pt_v2f v = __builtin_nontemporal_load((const pt_v2f*)p); return make_float2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+PT_DEV uint32_t ld_s(const uint32_t* p) {
+#if PT_STREAM_NT_LD
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+// A/B: PT_STREAM_ST_MODE = cache-policy modifiers of the state stores: 1 "sc1", 2 "sc0 sc1", 3 "sc0", 4 "nt sc1"
+#if defined(PT_STREAM_ST_MODE) && PT_STREAM_ST_MODE == 1
+#define PT_STREAM_ST_MOD "sc1"
+#elif defined(PT_STREAM_ST_MODE) && PT_STREAM_ST_MODE == 2
+#define PT_STREAM_ST_MOD "sc0 sc1"
+#elif defined(PT_STREAM_ST_MODE) && PT_STREAM_ST_MODE == 3
+#define PT_STREAM_ST_MOD "sc0"
+#elif defined(PT_STREAM_ST_MODE) && PT_STREAM_ST_MODE == 4
+#define PT_STREAM_ST_MOD "nt sc1"
+#endif
+#ifdef PT_STREAM_ST_MOD
+PT_DEV void st_s(float4* p, const float4 v) { const pt_v4f w = {v.x, v.y, v.z, v.w}; asm volatile("global_store_dwordx4 %0, %1, off " PT_STREAM_ST_MOD : : "v"(p), "v"(w) : "memory"); }
+PT_DEV void st_s(uint4* p, const uint4 v) { const pt_v4u w = {v.x, v.y, v.z, v.w}; asm volatile("global_store_dwordx4 %0, %1, off " PT_STREAM_ST_MOD : : "v"(p), "v"(w) : "memory"); }
+PT_DEV void st_s(float2* p, const float2 v) { const pt_v2f w = {v.x, v.y}; asm volatile("global_store_dwordx2 %0, %1, off " PT_STREAM_ST_MOD : : "v"(p), "v"(w) : "memory"); }
+#else
+PT_DEV void st_s(float4* p, const float4 v) {
+#if PT_STREAM_NT_ST
+    const pt_v4f w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, (pt_v4f*)p);
+#else
+    *p = v;
+#endif
+}
+PT_DEV void st_s(uint4* p, const uint4 v) {
+#if PT_STREAM_NT_ST
+    const pt_v4u w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, (pt_v4u*)p);
+#else
+    *p = v;
+#endif
+}
+PT_DEV void st_s(float2* p, const float2 v) {
+#if PT_STREAM_NT_ST
+    const pt_v2f w = {v.x, v.y}; __builtin_nontemporal_store(w, (pt_v2f*)p);
+#else
+    *p = v;
+#endif
+}
+#endif
+
 enum : uint32_t {
     F_REFR = 1,       // bRefracted of the current sample (loop-carried, Q8)
     F_NEEOK = 2,      // !isnan(brdfcos) of the current sample's pending NEE term
@@ -150,12 +230,13 @@ PT_DEV bool bounce(const DevScene& sc, const DevParams& prm, int prim, float t, 
     st.lightP = lightP;
     st.denom = sqlen(s.p - lightP) * pdfLight;
     // Dead NEE terms need no shadow ray.  The term ((wb * Le) * cosA) / denom (GetLightColor's result times :271-272) depends on the
-    // shadow ray only through Le, which is 0 or a primitive's emittance (finite and >= 0: checked at upload, DevScene::nee_prune).
+    // shadow ray only through Le, which is 0 or a primitive's emittance (finite, >= 0 and <= 1e8: checked at upload, DevScene::nee_prune).
     //  * brdfcos NaN: the reference skips the term (:271), nobody reads the ray;
     //  * every component of wb an exact zero (the light is below the surface's horizon: eval returns 0), cosA finite and
     //    0 < denom < inf: wb * Le = +-0 whatever Le is, so the term is +-0, and adding +-0 never changes a radiance (a radiance
     //    component is never -0: it starts as +0 and only (-0) + (-0) gives -0);
-    //  * cosA exactly 0 with |wb| < 1e30 and 0 < denom < inf: (wb * Le) is finite, times 0 is +-0, same argument.
+    //  * cosA exactly 0 with |wb| < 1e30 and 0 < denom < inf: (wb * Le) is finite (nee_prune also says every Le <= 1e8), times 0 is +-0,
+    //    same argument.
     // Everything else — including the NaN-producing corner cases, which must be reproduced — keeps its ray.
     {
         const float kInf = __builtin_inff();
@@ -215,12 +296,12 @@ PT_DEV bool shade_step_t(const DevScene& sc, const DevCamera& cam, const DevPara
     if (!(flags & F_PRIMARY)) h0 = *hit0Ptr;
 
     auto add_to_pixel = [&](const f3& r) {                                  // pathtracer.cu:79
-        if (!st.pixLoaded) { const float4 pq = *pixPtr; st.pixelColor = f3(pq.x, pq.y, pq.z); st.pixLoaded = true; }
+        if (!st.pixLoaded) { const float4 pq = ld_s(pixPtr); st.pixelColor = f3(pq.x, pq.y, pq.z); st.pixLoaded = true; }
         st.pixelColor += r;
     };
     // ---- a. the older closed sample: its last NEE term, then it joins the pixel ----
     if (flags & F_SHADOWA) {
-        const float4 ra = b.radA[sid], wa = b.wbA[sid], la = b.lpA[sid], ao = b.ray_o[2][sid], ad = b.ray_d[2][sid];
+        const float4 ra = ld_s(&b.radA[sid]), wa = ld_s(&b.wbA[sid]), la = ld_s(&b.lpA[sid]), ao = ld_s(&b.ray_o[2][sid]), ad = ld_s(&b.ray_d[2][sid]);
         f3 radA(ra.x, ra.y, ra.z);
         const f3 Le = nee_light_color(f3(ao.x, ao.y, ao.z), f3(ad.x, ad.y, ad.z), f3(la.x, la.y, la.z), hitA.x, primA,
                                       (primA < sc.n_tris) ? f3(emA.x, emA.y, emA.z) : prim_emittance(sc, primA < 0 ? 0 : primA));
@@ -259,15 +340,15 @@ PT_DEV bool shade_step_t(const DevScene& sc, const DevCamera& cam, const DevPara
             if (go) {
                 if (closing) {
                     // the closed sample waits in slot A for its shadow ray; the pixel gets it first thing next step
-                    b.radA[sid] = make_float4(st.radiance.x, st.radiance.y, st.radiance.z, st.denom);
-                    b.wbA[sid] = make_float4(st.wb.x, st.wb.y, st.wb.z, st.cosA);
-                    b.lpA[sid] = make_float4(st.lightP.x, st.lightP.y, st.lightP.z, 0.f);
-                    b.ray_o[2][sid] = make_float4(st.shO.x, st.shO.y, st.shO.z, st.shTmax);
-                    b.ray_d[2][sid] = make_float4(st.shD.x, st.shD.y, st.shD.z, shadow_stop_t(st.shO, st.shTmax));
+                    st_s(&b.radA[sid], make_float4(st.radiance.x, st.radiance.y, st.radiance.z, st.denom));
+                    st_s(&b.wbA[sid], make_float4(st.wb.x, st.wb.y, st.wb.z, st.cosA));
+                    st_s(&b.lpA[sid], make_float4(st.lightP.x, st.lightP.y, st.lightP.z, 0.f));
+                    st_s(&b.ray_o[2][sid], make_float4(st.shO.x, st.shO.y, st.shO.z, st.shTmax));
+                    st_s(&b.ray_d[2][sid], make_float4(st.shD.x, st.shD.y, st.shD.z, shadow_stop_t(st.shO, st.shTmax)));
                     shA = true; neeA = neeCur; shCur = false; neeCur = false; closing = false;
                 }
                 prim = __float_as_int(h0.y); t = h0.x;
-                const float4 d0 = *dir0Ptr;
+                const float4 d0 = ld_s(dir0Ptr);
                 rorg = f3(cam.pos[0], cam.pos[1], cam.pos[2]); rdir = f3(d0.x, d0.y, d0.z);
                 if (prim < 0) {
                     // the pixel looks past the scene: every remaining sample is the ambient term (no draws, no rays)
@@ -317,15 +398,15 @@ PT_DEV bool shade_step_t(const DevScene& sc, const DevCamera& cam, const DevPara
         if (!go && (!cur || closing) && st.toStart > 0) {
             if (closing) {
                 // the closed sample waits in slot A for its shadow ray; the pixel gets it first thing next step
-                b.radA[sid] = make_float4(st.radiance.x, st.radiance.y, st.radiance.z, st.denom);
-                b.wbA[sid] = make_float4(st.wb.x, st.wb.y, st.wb.z, st.cosA);
-                b.lpA[sid] = make_float4(st.lightP.x, st.lightP.y, st.lightP.z, 0.f);
-                b.ray_o[2][sid] = make_float4(st.shO.x, st.shO.y, st.shO.z, st.shTmax);
-                b.ray_d[2][sid] = make_float4(st.shD.x, st.shD.y, st.shD.z, shadow_stop_t(st.shO, st.shTmax));
+                st_s(&b.radA[sid], make_float4(st.radiance.x, st.radiance.y, st.radiance.z, st.denom));
+                st_s(&b.wbA[sid], make_float4(st.wb.x, st.wb.y, st.wb.z, st.cosA));
+                st_s(&b.lpA[sid], make_float4(st.lightP.x, st.lightP.y, st.lightP.z, 0.f));
+                st_s(&b.ray_o[2][sid], make_float4(st.shO.x, st.shO.y, st.shO.z, st.shTmax));
+                st_s(&b.ray_d[2][sid], make_float4(st.shD.x, st.shD.y, st.shD.z, shadow_stop_t(st.shO, st.shTmax)));
                 shA = true; neeA = neeCur; shCur = false; neeCur = false; closing = false;
             }
             prim = __float_as_int(h0.y); t = h0.x;
-            const float4 d0 = *dir0Ptr;
+            const float4 d0 = ld_s(dir0Ptr);
             rorg = f3(cam.pos[0], cam.pos[1], cam.pos[2]); rdir = f3(d0.x, d0.y, d0.z);
             if (prim < 0) {
                 // the pixel looks past the scene: every remaining sample is the ambient term (no draws, no rays)
@@ -368,19 +449,19 @@ PT_DEV bool shade_step(const DevScene& sc, const DevCamera& cam, const DevParams
 
 PT_DEV void load_state(const WfBuf& b, uint32_t sid, SState& st)
 {
-    const uint4 r0 = b.rng0[sid], r1 = b.rng1[sid];
+    const uint4 r0 = ld_s(&b.rng0[sid]), r1 = ld_s(&b.rng1[sid]);
     st.rng.x0 = r0.x; st.rng.x1 = r0.y; st.rng.x2 = r0.z; st.rng.x3 = r0.w; st.rng.x4 = r1.x; st.rng.d = r1.y;
     st.toStart = (int)(r1.z >> 16); st.depth = (int)((r1.z >> 8) & 0xff); st.refractCnt = (int)(r1.z & 0xff);
     st.flags = r1.w;
-    const float4 wq = b.weight[sid], rq4 = b.rad[sid];
+    const float4 wq = ld_s(&b.weight[sid]), rq4 = ld_s(&b.rad[sid]);
     st.weight = f3(wq.x, wq.y, wq.z); st.radiance = f3(rq4.x, rq4.y, rq4.z);
     st.cosA = wq.w; st.denom = rq4.w;
     st.pixelColor = f3(0.f, 0.f, 0.f); st.pixLoaded = false;
     // the current sample's rays and pending NEE term are fetched whatever the flags say (stale values are
     // never used): nearly every step has them, and waiting for the flags first only adds latency
-    const float4 po = b.ray_o[0][sid], pd = b.ray_d[0][sid];
+    const float4 po = ld_s(&b.ray_o[0][sid]), pd = ld_s(&b.ray_d[0][sid]);
     st.pathO = f3(po.x, po.y, po.z); st.pathD = f3(pd.x, pd.y, pd.z);
-    const float4 so = b.ray_o[1][sid], sd = b.ray_d[1][sid], lpq = b.lp[sid], wbq = b.wb[sid];
+    const float4 so = ld_s(&b.ray_o[1][sid]), sd = ld_s(&b.ray_d[1][sid]), lpq = ld_s(&b.lp[sid]), wbq = ld_s(&b.wb[sid]);
     st.shO = f3(so.x, so.y, so.z); st.shD = f3(sd.x, sd.y, sd.z); st.shTmax = so.w;
     st.lightP = f3(lpq.x, lpq.y, lpq.z); st.wb = f3(wbq.x, wbq.y, wbq.z);
 }
@@ -395,20 +476,20 @@ PT_DEV void write_mean(const WfBuf& b, const DevParams& prm, uint32_t sid, const
 PT_DEV void store_state(const WfBuf& b, uint32_t slot, const SState& st)
 {
     const uint32_t nf = st.flags;
-    b.rng0[slot] = make_uint4(st.rng.x0, st.rng.x1, st.rng.x2, st.rng.x3);
-    b.rng1[slot] = make_uint4(st.rng.x4, st.rng.d, ((uint32_t)st.toStart << 16) | ((uint32_t)st.depth << 8) | (uint32_t)st.refractCnt, nf);
-    b.weight[slot] = make_float4(st.weight.x, st.weight.y, st.weight.z, st.cosA);
-    b.rad[slot] = make_float4(st.radiance.x, st.radiance.y, st.radiance.z, st.denom);
-    if (st.pixLoaded) b.pix[slot] = make_float4(st.pixelColor.x, st.pixelColor.y, st.pixelColor.z, 0.f);
+    st_s(&b.rng0[slot], make_uint4(st.rng.x0, st.rng.x1, st.rng.x2, st.rng.x3));
+    st_s(&b.rng1[slot], make_uint4(st.rng.x4, st.rng.d, ((uint32_t)st.toStart << 16) | ((uint32_t)st.depth << 8) | (uint32_t)st.refractCnt, nf));
+    st_s(&b.weight[slot], make_float4(st.weight.x, st.weight.y, st.weight.z, st.cosA));
+    st_s(&b.rad[slot], make_float4(st.radiance.x, st.radiance.y, st.radiance.z, st.denom));
+    if (st.pixLoaded) st_s(&b.pix[slot], make_float4(st.pixelColor.x, st.pixelColor.y, st.pixelColor.z, 0.f));
     if (nf & F_SHADOW) {
-        b.ray_o[1][slot] = make_float4(st.shO.x, st.shO.y, st.shO.z, st.shTmax);
-        b.ray_d[1][slot] = make_float4(st.shD.x, st.shD.y, st.shD.z, shadow_stop_t(st.shO, st.shTmax));
-        b.wb[slot] = make_float4(st.wb.x, st.wb.y, st.wb.z, 0.f);
-        b.lp[slot] = make_float4(st.lightP.x, st.lightP.y, st.lightP.z, 0.f);
+        st_s(&b.ray_o[1][slot], make_float4(st.shO.x, st.shO.y, st.shO.z, st.shTmax));
+        st_s(&b.ray_d[1][slot], make_float4(st.shD.x, st.shD.y, st.shD.z, shadow_stop_t(st.shO, st.shTmax)));
+        st_s(&b.wb[slot], make_float4(st.wb.x, st.wb.y, st.wb.z, 0.f));
+        st_s(&b.lp[slot], make_float4(st.lightP.x, st.lightP.y, st.lightP.z, 0.f));
     }
     if (nf & F_PATH) {
-        b.ray_o[0][slot] = make_float4(st.pathO.x, st.pathO.y, st.pathO.z, 999999.f);
-        b.ray_d[0][slot] = make_float4(st.pathD.x, st.pathD.y, st.pathD.z, -__builtin_inff());
+        st_s(&b.ray_o[0][slot], make_float4(st.pathO.x, st.pathO.y, st.pathO.z, 999999.f));
+        st_s(&b.ray_d[0][slot], make_float4(st.pathD.x, st.pathD.y, st.pathD.z, -__builtin_inff()));
     }
 }
 

@@ -152,6 +152,9 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
               int topWant, unsigned long long* stat, int statLaunch)
 {
     constexpr bool STAT = MODE == 1 || MODE == 3, HIST = MODE == 1, timeline = MODE != 0;
+    // PUBLISH launches share the chip with wf_shade's early phase: the traversal is the critical path of the iteration (its last waves
+    // run a serial chain), so its waves issue ahead of the shading waves (statLaunch carries the priority in the production build)
+    if (PUBLISH && MODE == 0) { if (statLaunch == 1) __builtin_amdgcn_s_setprio(1); else if (statLaunch == 2) __builtin_amdgcn_s_setprio(2); else if (statLaunch == 3) __builtin_amdgcn_s_setprio(3); }
     const unsigned long long stT0 = timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz
     unsigned long long stTExh = 0;
     unsigned long long stClk[5] = {0, 0, 0, 0, 0}, stMark = 0;      // STAT: shader clocks in refill / vote + budget / node step / triangle step / ray epilogue
@@ -263,7 +266,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                         const uint32_t qid = b.rq[0][q + (k0 ? 0u : (k1 ? n16 - nPath : 2u * n16 - nKind1))];
                         const uint32_t kn = k0 ? 0u : (k1 ? n16 : 2u * n16);              // kind * n16
                         hs = kn + (qid & ~kResumeBit);
-                        const float4 o = b.ray_o[0][hs + kn], d = b.ray_d[0][hs + kn];
+                        const float4 o = ld_s(&b.ray_o[0][hs + kn]), d = ld_s(&b.ray_d[0][hs + kn]);
                         const int kind = k0 ? 0 : 1;      // all that is still asked of it: path ray or not
                         org = f3(o.x, o.y, o.z); dir = f3(d.x, d.y, d.z);
                         ray_setup(dir, inv, cscale, degenerate);      // pt_trace.h
@@ -456,7 +459,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     if (sphere_root(f3(c.x, c.y, c.z), c.w, org, dir, bestT, root)) { bestT = root; bestPrim = sc.n_tris + s; }
                 }
                 if (PUBLISH) __hip_atomic_store((unsigned long long*)&b.hit[0][hs], (unsigned long long)__float_as_uint(bestT) | ((unsigned long long)(uint32_t)bestPrim << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else b.hit[0][hs] = make_float2(bestT, __int_as_float(bestPrim));
+                else st_s(&b.hit[0][hs], make_float2(bestT, __int_as_float(bestPrim)));
                 hasRay = false;
                 if (STAT) stRays++;
                 if (HIST) atomicAdd(&stat[8 + 3 * 2700 + 32 + 2700 + (steps >= 252 ? 63 : steps >> 2)], 1ull);      // node steps of this ray (this launch), bins of 4
@@ -523,7 +526,7 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
     uint32_t sid = 0, resume = 0;      // resume: the queued rays are suspended traversals (wf_trace then reads their records)
     bool step = have;
     if (have) {
-        sid = b.active[listIn][idx];
+        sid = ld_s(&b.active[listIn][idx]);
         if (PHASE == 2) {
             const uint32_t r = b.res[idx];
             if (r & R_DONE) {      // shaded by phase 1: only the appends are left
@@ -536,7 +539,7 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
         SState st;
         float2 hitP, hitS, hitA;
         if (PHASE == 1) { hitP = load_hit_coherent(&b.hit[0][sid]); hitS = load_hit_coherent(&b.hit[1][sid]); hitA = load_hit_coherent(&b.hit[2][sid]); }
-        else { hitP = b.hit[0][sid]; hitS = b.hit[1][sid]; hitA = b.hit[2][sid]; }      // same fetch level as the state
+        else { hitP = ld_s(&b.hit[0][sid]); hitS = ld_s(&b.hit[1][sid]); hitA = ld_s(&b.hit[2][sid]); }      // same fetch level as the state
         load_state(b, sid, st);
         // a ray of this stream is still being traversed (time-sliced): wait one iteration
         const int pendP = (st.flags & F_PATH) ? __float_as_int(hitP.y) : -1, pendS = (st.flags & F_SHADOW) ? __float_as_int(hitS.y) : -1;
@@ -762,6 +765,9 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     // two per CU; other shapes re-measured after that change: 256 threads -4 %, 384 / 768 -13 %, 1024 -8 %, 3 waves/SIMD -9...-13 %
     // (profiles/r02_experiments/r02_t16_shade_shapes_after_noslp.log)
     static const int shadeThreads = (getenv("PTAMD_ST") && atoi(getenv("PTAMD_ST")) >= 64 && atoi(getenv("PTAMD_ST")) <= kShadeThreads) ? (atoi(getenv("PTAMD_ST")) & ~63) : 512;
+    static const int earlyPrio = getenv("PTAMD_EPRIO") ? atoi(getenv("PTAMD_EPRIO")) : 0;          // issue priority of the traversal waves while wf_shade's early phase runs beside them
+    static const bool pubOnly = getenv("PTAMD_EPUB") && atoi(getenv("PTAMD_EPUB")) != 0;          // A/B: device-scope hit stores and marks, but no early phase
+    static const int earlyThreads = (getenv("PTAMD_EST") && atoi(getenv("PTAMD_EST")) >= 64 && atoi(getenv("PTAMD_EST")) <= kShadeThreads) ? (atoi(getenv("PTAMD_EST")) & ~63) : 256;
     static const int refillMin = getenv("PTAMD_RF") ? atoi(getenv("PTAMD_RF")) : kWfRefill;     // idle lanes that trigger a refill
     static const int triTrig = getenv("PTAMD_TT") ? atoi(getenv("PTAMD_TT")) : 64;
     static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
@@ -783,11 +789,11 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             const int sIn = it % 3, sOut = (it + 1) % 3, sClr = (it + 2) % 3;
             const bool timed = trace_ev && it < trace_ev_pairs;
             if (timed) (void)hipEventRecord(trace_ev[3 * it], stream);
-            // early shade (wf_shade PHASE 1 / 2): once few enough streams are alive that the traversal's launch tail is a large part
-            // of an iteration, the shade step starts on `aux` beside the draining wf_trace and the rest follows both (result-neutral).
-            // `marks`: every shade launch of this render sets the not-ready marks, so that the switch can happen at any iteration.
-            const bool marks = aux != nullptr && earlyBelow > 0;
-            const bool early = marks && !traceStat && liveBound <= (uint32_t)earlyBelow;
+            // early shade (wf_shade PHASE 1 / 2): for a render of few enough streams that the traversal's launch tail is a large part of
+            // every iteration (one rank of an 8-way tile split), the shade step starts on `aux` beside the draining wf_trace and the rest
+            // follows both (result-neutral).  Decided once per render: a large render gains nothing from it in its last iterations.
+            const bool early = aux != nullptr && earlyBelow > 0 && nStreams <= (size_t)earlyBelow && !traceStat && !pubOnly;
+            const bool marks = early || pubOnly;
             if (early) {
                 // aux may start once the previous iteration's shade (everything on `stream` so far) is done
                 if ((e = hipEventRecord(evOvl[it & 1], stream)) != hipSuccess) return e;
@@ -796,14 +802,17 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             if (traceStat && traceStatClk) hipLaunchKernelGGL(wf_trace<3>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
             else if (traceStat && traceStatFull) hipLaunchKernelGGL(wf_trace<1>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
             else if (traceStat) hipLaunchKernelGGL(wf_trace<2>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
-            else if (early) hipLaunchKernelGGL((wf_trace<0, true>), dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, 0);
+            else if (early || pubOnly) hipLaunchKernelGGL((wf_trace<0, true>), dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, earlyPrio);
             else hipLaunchKernelGGL(wf_trace<0>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, 0);
             if (timed) (void)hipEventRecord(trace_ev[3 * it + 1], stream);
             const dim3 sg((liveBound + shadeThreads - 1) / shadeThreads), sb(shadeThreads);
             const bool twoRounds = shadeRounds >= 0 ? (shadeRounds != 0) : (liveBound < trStreams);
 #define PT_SHADE(W, T, P, M, S) hipLaunchKernelGGL((wf_shade<W, T, P, M>), sg, sb, 0, S, *sc, *cam, prm, b, sIn, sOut, sClr, it & 1)
             if (early) {
-                if (twoRounds) PT_SHADE(4, true, 1, true, aux); else PT_SHADE(4, false, 1, true, aux);
+                // phase 1 in small workgroups: a 256-thread workgroup needs one free wave slot per SIMD, i.e. two traversal workgroups of
+                // the CU gone, a 512-thread one four — it gets onto the chip earlier in the drain
+                { const dim3 sg((liveBound + earlyThreads - 1) / earlyThreads), sb(earlyThreads);
+                  if (twoRounds) PT_SHADE(4, true, 1, true, aux); else PT_SHADE(4, false, 1, true, aux); }
                 if ((e = hipEventRecord(evOvl[2 + (it & 1)], aux)) != hipSuccess) return e;
                 if ((e = hipStreamWaitEvent(stream, evOvl[2 + (it & 1)], 0)) != hipSuccess) return e;
                 if (twoRounds) PT_SHADE(4, true, 2, true, stream); else PT_SHADE(4, false, 2, true, stream);

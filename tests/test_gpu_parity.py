@@ -343,8 +343,8 @@ def test_shading_schedule_switches_inside_a_render():
 
 def test_early_shade_is_result_neutral():
     """pt_set_early_shade: the shade step starts on a second stream beside the draining traversal kernel (streams whose rays are all back),
-    the rest follows.  Same bits as the one-launch step — always on, switched on part-way through a render as streams retire, with
-    both shading schedules, with spheres (all four lobes) and time-sliced rays — and the same bits as the oracle's golden image."""
+    the rest follows.  Same bits as the one-launch step — on and off by the render's stream count, with both shading schedules, with
+    spheres (all four lobes) —, for a small frame and for one rank of an 8-way split of the 1080p frame (the size the feature is for)."""
     prims = ptamd.gen_scene(1, 24)
     nodes, tris, _ = ptamd.build_bvh(prims)
     sph = make_test_spheres()
@@ -356,7 +356,7 @@ def test_early_shade_is_result_neutral():
     assert np.isfinite(base).all() and base.mean() > 0.05
     for rounds in (1, 0):
         sc.set_shade_rounds(rounds)
-        for below in (1 << 30, 9000, 1):      # always / from the point where 9,000 of the 28,800 streams are left / only for the very last stream
+        for below in (1 << 30, 28800, 28799):      # on / on (the render has exactly 28,800 streams) / off
             sc.set_early_shade(below)
             assert np.array_equal(bits(sc.render(cam, prm)), bits(base)), (rounds, below)
     # a larger frame: a window of 1080p rendered as one rank of an 8-way split (the size the feature is for) against the plain step
@@ -371,6 +371,30 @@ def test_early_shade_is_result_neutral():
         out.append(tr.render().cpu().numpy().copy())
     assert np.isfinite(out[0]).all() and out[0].mean() > 0.05
     assert np.array_equal(bits(out[0]), bits(out[1]))
+
+
+def test_very_bright_light_keeps_its_shadow_rays():
+    """Dead-NEE pruning assumes (weight * brdfcos) * Le stays finite (pt_stream.h: bounce); the upload switches it off for a scene with
+    an emittance above 1e8, where the product can overflow and the reference then adds inf * 0 = NaN (include/CudaUtil.cuh:271-272).
+    With a light of 3e38 the frame is mostly inf / NaN — and must be so exactly where the oracle's is."""
+    from scenes_util import V_EMIT
+    prims = ptamd.gen_scene(1, 16).copy().reshape(-1, 3, 28)
+    lit = prims[:, 0, V_EMIT] > 0
+    assert lit.sum() == 2
+    prims[lit, :, V_EMIT:V_EMIT + 3] = np.float32(3e38)
+    prims = prims.reshape(-1, 84)
+    nodes, tris, _ = ptamd.build_bvh(prims)
+    W, H = 64, 48
+    img = ptamd.Scene(nodes, tris).render(ptamd.make_camera(W, H), ptamd.default_params(passes=2, spp_per_pass=16))
+    ref, _ = O.Scene(nodes.tobytes(), tris).render(O.make_camera(W, H), O.make_params(W, H, 2, 16), 8)
+    assert same_bits_or_nan(img, ref).all()
+    assert np.isnan(ref).any() or np.isinf(ref).any()
+    # the same scene with an ordinary light still prunes and still matches (the guard is per scene)
+    prims = prims.reshape(-1, 3, 28); prims[lit, :, V_EMIT:V_EMIT + 3] = np.float32(9e7); prims = prims.reshape(-1, 84)
+    nodes, tris, _ = ptamd.build_bvh(prims)
+    img = ptamd.Scene(nodes, tris).render(ptamd.make_camera(W, H), ptamd.default_params(passes=1, spp_per_pass=8))
+    ref, _ = O.Scene(nodes.tobytes(), tris).render(O.make_camera(W, H), O.make_params(W, H, 1, 8), 8)
+    assert same_bits_or_nan(img, ref).all() and np.isfinite(ref).all()
 
 
 def test_error_paths():
