@@ -71,10 +71,28 @@ def gen_png():
     print("ref_png.npz", {k: v.shape for k, v in out.items()})
 
 
+def gen_rocrand():
+    """ref_rocrand_xorwow.npz: rocRAND's own XORWOW engine (oracle/rocrand_ref.cpp, host build of /opt/rocm/include/rocrand/rocrand_xorwow.h)
+    for the seeds the renderer uses: pixel offset + pass * W * H, small and beyond 2^32."""
+    seeds = np.array([0, 1, 2, 255, 256 * 256, 1920 * 1080 - 1, 1920 * 1080 * 7 + 12345, 2 ** 31 - 1, 2 ** 32 - 1, 2 ** 32 + 5, 2 ** 40 + 123456789,
+                      2 ** 63 + 17], dtype=np.uint64)
+    raw, uni = [], []
+    for s in seeds:
+        r, u = O.rocrand_ref(int(s), 96)
+        raw.append(r); uni.append(u)
+    np.savez_compressed(os.path.join(G, "ref_rocrand_xorwow.npz"), seeds=seeds, raw=np.stack(raw), uniform=np.stack(uni))
+    print("ref_rocrand_xorwow.npz", np.stack(raw).shape)
+
+
 def main():
     os.makedirs(G, exist_ok=True)
     if not O.have_ref():
         raise SystemExit("oracle/_ref/ptref missing: run `make -C oracle ref` first")
+    if len(sys.argv) > 1 and sys.argv[1] == "rocrand":
+        if not O.have_rocrand_ref():
+            raise SystemExit("oracle/_build/rocrand_ref missing: run `make -C oracle rocrand` first")
+        gen_rocrand()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "png":
         gen_png()
         return

@@ -296,3 +296,17 @@ def ref_png_read(path):
         raw = np.fromfile(o, np.uint8)
     W, H, C = (int(v) for v in raw[:12].view(np.int32))
     return raw[12:].reshape(H, W, C)
+
+
+ROCRAND_REF = os.path.join(ORACLE_DIR, "_build", "rocrand_ref")
+
+
+def have_rocrand_ref():
+    return os.path.exists(ROCRAND_REF) and os.access(ROCRAND_REF, os.X_OK)
+
+
+def rocrand_ref(seed, n):
+    """(raw uint32, uniform float32) of rocRAND's own XORWOW engine on the host: rocrand_init(seed, 0, 0) then n draws."""
+    out = subprocess.run([ROCRAND_REF, str(int(seed)), str(int(n))], check=True, capture_output=True, text=True).stdout.split()
+    a = np.array(out, dtype=np.uint64).astype(np.uint32).reshape(-1, 2)
+    return a[:, 0].copy(), a[:, 1].copy().view(np.float32)

@@ -46,6 +46,15 @@ def test_rng_words_and_uniforms_bit_exact():
         assert u_g.min() > 0.0 and u_g.max() <= 1.0
 
 
+def test_rng_matches_rocrand_engine_golden(golden_dir):
+    """The device RNG against rocRAND's own XORWOW engine (tests/golden/ref_rocrand_xorwow.npz, oracle/rocrand_ref.cpp): the published
+    implementation the RNG contract names."""
+    g = np.load(os.path.join(golden_dir, "ref_rocrand_xorwow.npz"))
+    for seed, raw, uni in zip(g["seeds"], g["raw"], g["uniform"]):
+        r_g, u_g = ptamd.dbg_rng(int(seed), raw.shape[0])
+        assert np.array_equal(r_g, raw) and np.array_equal(bits(u_g), bits(uni)), int(seed)
+
+
 def test_device_arithmetic_is_ieee_and_correctly_rounded():
     rs = np.random.RandomState(0)
     x = np.concatenate([rs.uniform(-7, 7, 100000), rs.uniform(-1e-3, 1e-3, 1000), 10.0 ** rs.uniform(-6, 6, 5000)]).astype(np.float32)

@@ -99,3 +99,24 @@ def test_live_against_reference_binary():
     n_r, t_r = O.ref_bvh(prims)
     n_o, t_o, _ = O.bvh_build(prims)
     assert n_r.tobytes() == n_o.tobytes() and np.array_equal(bits(t_r), bits(t_o))
+
+
+def test_xorwow_matches_rocrand_engine_golden(golden_dir):
+    """The RNG contract (XORWOW, rocRAND's seed scramble, subsequence 0, offset 0, uniform in (0, 1]) pinned to rocRAND's OWN
+    engine: tests/golden/ref_rocrand_xorwow.npz holds rocrand_init / rocrand / rocrand_uniform of /opt/rocm/include/rocrand/rocrand_xorwow.h
+    run on the host (oracle/rocrand_ref.cpp).  Raw words and uniforms, bit for bit, seeds up to 2^63."""
+    g = np.load(os.path.join(golden_dir, "ref_rocrand_xorwow.npz"))
+    for seed, raw, uni in zip(g["seeds"], g["raw"], g["uniform"]):
+        r_o, u_o = O.rng(int(seed), raw.shape[0])
+        assert np.array_equal(r_o, raw), int(seed)
+        assert np.array_equal(bits(u_o), bits(uni)), int(seed)
+        assert (uni > 0).all() and (uni <= 1).all()
+
+
+@pytest.mark.skipif(not O.have_rocrand_ref(), reason="oracle/_build/rocrand_ref not built (make -C oracle rocrand)")
+def test_xorwow_matches_rocrand_engine_live():
+    rs = np.random.RandomState(99)
+    for seed in [int(x) for x in rs.randint(0, 2 ** 62, 24, dtype=np.int64)] + [1920 * 1080 * 3 + 77]:
+        r_r, u_r = O.rocrand_ref(seed, 40)
+        r_o, u_o = O.rng(seed, 40)
+        assert np.array_equal(r_o, r_r) and np.array_equal(bits(u_o), bits(u_r)), seed
