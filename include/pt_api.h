@@ -301,7 +301,8 @@ PT_API int  pt_last_iterations(PtScene* s);
 PT_API int  pt_set_drain_threshold(PtScene* s, int32_t live_streams);
 /* Mode 1, early shade: in a render call of at most `max_streams` streams (pixels of this rank x passes of the call) the shade step of
  * every iteration starts on a second HIP stream beside the draining traversal kernel (streams whose rays are all back are shaded at
- * once, the others — and all list appends — follow when the traversal has finished); 0 = never, default 2,500,000: on for one rank of
+ * once, the others — and all list appends — follow when the traversal has finished); renders of fewer than max_streams / 8 streams are
+ * left alone too (launch-latency bound); 0 = never, default 2,500,000: on for one rank of
  * an 8-way tile split of 1080p x 8 passes (-6.5 % time), off for a full frame (whose launches are large next to the traversal's
  * ~0.3 ms launch tail).  Result-neutral: every stream goes through the same step (pathtrace-on-cuda_amd/csrc/pt_wavefront.hip:
  * wf_shade PHASE 1 / 2).  Environment PTAMD_EARLY overrides the default. */

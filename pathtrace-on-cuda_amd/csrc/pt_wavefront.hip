@@ -792,7 +792,8 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             // early shade (wf_shade PHASE 1 / 2): for a render of few enough streams that the traversal's launch tail is a large part of
             // every iteration (one rank of an 8-way tile split), the shade step starts on `aux` beside the draining wf_trace and the rest
             // follows both (result-neutral).  Decided once per render: a large render gains nothing from it in its last iterations.
-            const bool early = aux != nullptr && earlyBelow > 0 && nStreams <= (size_t)earlyBelow && !traceStat && !pubOnly;
+            // (not below ~1/8 of the limit either: a render that small is bound by launch latency, and this adds a launch and two waits per iteration)
+            const bool early = aux != nullptr && earlyBelow > 0 && nStreams <= (size_t)earlyBelow && nStreams >= (size_t)earlyBelow / 8 && !traceStat && !pubOnly;
             const bool marks = early || pubOnly;
             if (early) {
                 // aux may start once the previous iteration's shade (everything on `stream` so far) is done

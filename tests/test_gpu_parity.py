@@ -365,7 +365,7 @@ def test_early_shade_is_result_neutral():
     assert np.isfinite(base).all() and base.mean() > 0.05
     for rounds in (1, 0):
         sc.set_shade_rounds(rounds)
-        for below in (1 << 30, 28800, 28799):      # on / on (the render has exactly 28,800 streams) / off
+        for below in (28800 * 8, 28800, 28799, 28800 * 8 + 8):      # on / on (the render has exactly 28,800 streams) / off (too many) / off (too few)
             sc.set_early_shade(below)
             assert np.array_equal(bits(sc.render(cam, prm)), bits(base)), (rounds, below)
     # a larger frame: a window of 1080p rendered as one rank of an 8-way split (the size the feature is for) against the plain step
@@ -374,7 +374,7 @@ def test_early_shade_is_result_neutral():
     import torch
     from ptamd.dist import TileRenderer
     out = []
-    for below in (0, 1 << 30):
+    for below in (0, 4000000):
         big.set_early_shade(below)
         tr = TileRenderer(big, cam, ptamd.default_params(passes=2, spp_per_pass=4, rank=3, world=8), torch.device("cuda:0"))
         out.append(tr.render().cpu().numpy().copy())
