@@ -145,127 +145,8 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
 // some occluder, for which wf_shade's |hit.p - P| < EPS test fails exactly as it would for the
 // closest one.
 // ---------------------------------------------------------------------------------------
-// ---------------------------------------------------------------------------------------
-// quad_tail: the end of a launch, four lanes per ray (round 3).
-// When the queue has run dry a wave only empties out, and the launch ends when the LONGEST ray in flight has done its ~60-100
-// steps at the pace of a lone wave: ~3 us per trip, of which ~2 us are the wave's own serial instruction issue (380 instructions a
-// trip at one per ~5 clocks) for a handful of live lanes.  Once a wave is down to <= 16 rays it therefore re-deals them: ray s goes
-// to lanes 4s .. 4s+3, and a step costs each lane a quarter of the arithmetic — lane j tests child j of the node (one slab test
-// instead of four, no sort: the four entry distances are ranked across the quad with DPP broadcasts, the hit children are written
-// to the ray's stack in parallel) or triangle j of the leaf (a leaf is tested in the trip that reaches it: no parking, no vote).
-// The ray's stack stays where it is (the LDS column of the lane that owned it).  Result-neutral: the same slab arithmetic, the
-// same Triangle::hit + reference-leaf-box acceptance (tri_test), and the closest hit under the tie rule does not depend on the
-// order of the tests.  The node budget does not apply here (a ray that is in this phase is what the launch is waiting for).
-// ---------------------------------------------------------------------------------------
-template <int I> PT_DEV int quad_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, I * 0x55, 0xf, 0xf, true); }      // quad_perm:[I,I,I,I]
-
-template <bool PUBLISH>
-PT_DEV void quad_tail(const DevScene& sc, const WfBuf& b, int* stackWave, int* ovfWave, int ovfStride, int* ldsQ,
-                      bool hasRay, f3 org, f3 dir, f3 inv, float bestT, float cscale, float stopBelow, int bestPrim, int cur, int sp, int pend,
-                      bool degenerate, uint32_t hs)
-{
-    const int lane = threadIdx.x & 63;
-    // every ray's state in the form (cur, stack): a parked leaf goes back on the stack
-    if (hasRay && pend != 0) {
-        if (cur == kDone) cur = pend;
-        else { if (sp < kWfLdsStack) stackWave[sp * 64 + lane] = pend; else ovfWave[(sp - kWfLdsStack) * ovfStride + lane] = pend; sp++; }
-    }
-    // ---- re-deal: the s-th live ray to lanes 4s .. 4s+3 ----
-    const unsigned long long liveM = __ballot(hasRay);
-    const int nLive = __builtin_popcountll(liveM);
-    if (hasRay) ldsQ[__builtin_popcountll(liveM & ((1ull << lane) - 1ull))] = lane;
-    const int slot = lane >> 2, j = lane & 3;
-    bool alive = slot < nLive;
-    const int col = alive ? ldsQ[slot] : lane;      // the lane that owned the ray: its column holds the ray's stack
-    org.x = __shfl(org.x, col); org.y = __shfl(org.y, col); org.z = __shfl(org.z, col);
-    dir.x = __shfl(dir.x, col); dir.y = __shfl(dir.y, col); dir.z = __shfl(dir.z, col);
-    inv.x = __shfl(inv.x, col); inv.y = __shfl(inv.y, col); inv.z = __shfl(inv.z, col);
-    bestT = __shfl(bestT, col); cscale = __shfl(cscale, col); stopBelow = __shfl(stopBelow, col);
-    bestPrim = __shfl(bestPrim, col); cur = __shfl(cur, col); sp = __shfl(sp, col);
-    degenerate = __shfl((int)degenerate, col) != 0;
-    hs = (uint32_t)__shfl((int)hs, col);
-    auto st_store = [&](int k, int v) { if (k < kWfLdsStack) stackWave[k * 64 + col] = v; else ovfWave[(k - kWfLdsStack) * ovfStride + col] = v; };
-    auto st_load = [&](int k) -> int {
-        int v = stackWave[(k < kWfLdsStack ? k : 0) * 64 + col];
-        asm volatile("" : "+v"(v));
-        if (k >= kWfLdsStack) v = ovfWave[(k - kWfLdsStack) * ovfStride + col];
-        return v;
-    };
-    while (__ballot(alive) != 0ull) {
-        if (alive) {
-            if (cur >= 0) {
-                // ---- node step, lane j = child j (the arithmetic of wf_trace's node step for one child) ----
-                const uint4* np = sc.quad + 4 * (size_t)cur;
-                const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-                const float Ax = inv.x * __uint_as_float(n0.w), Ay = inv.y * __uint_as_float(n3.z), Az = inv.z * __uint_as_float(n3.w);
-                const float Bx = (__uint_as_float(n0.x) - org.x) * inv.x;
-                const float By = (__uint_as_float(n0.y) - org.y) * inv.y;
-                const float Bz = (__uint_as_float(n0.z) - org.z) * inv.z;
-                const float kSl = 9.5367431640625e-7f;                           // 2^-20
-                const float sx = (__builtin_fabsf(Bx) + 255.f * __builtin_fabsf(Ax)) * kSl;
-                const float sy = (__builtin_fabsf(By) + 255.f * __builtin_fabsf(Ay)) * kSl;
-                const float sz = (__builtin_fabsf(Bz) + 255.f * __builtin_fabsf(Az)) * kSl;
-                const bool negx = __float_as_int(inv.x) < 0, negy = __float_as_int(inv.y) < 0, negz = __float_as_int(inv.z) < 0;
-                const int sh = 8 * j;
-                const float lox = (float)((n2.x >> sh) & 0xffu), hix = (float)((n2.w >> sh) & 0xffu);
-                const float loy = (float)((n2.y >> sh) & 0xffu), hiy = (float)((n3.x >> sh) & 0xffu);
-                const float loz = (float)((n2.z >> sh) & 0xffu), hiz = (float)((n3.y >> sh) & 0xffu);
-                const float tnx = __builtin_fmaf(negx ? hix : lox, Ax, Bx - sx), tfx = __builtin_fmaf(negx ? lox : hix, Ax, Bx + sx);
-                const float tny = __builtin_fmaf(negy ? hiy : loy, Ay, By - sy), tfy = __builtin_fmaf(negy ? loy : hiy, Ay, By + sy);
-                const float tnz = __builtin_fmaf(negz ? hiz : loz, Az, Bz - sz), tfz = __builtin_fmaf(negz ? loz : hiz, Az, Bz + sz);
-                const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.f));
-                const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, bestT * cscale));
-                const int key = (tn <= tf) ? __float_as_int(tn) : 0x7fffffff;
-                const int ref = j == 0 ? (int)n1.x : (j == 1 ? (int)n1.y : (j == 2 ? (int)n1.z : (int)n1.w));
-                const int k0 = quad_bcast<0>(key), k1 = quad_bcast<1>(key), k2 = quad_bcast<2>(key), k3 = quad_bcast<3>(key);
-                // rank of this child among the four by entry distance (equal distances: by slot), number of hit children
-                const int rank = (int)(k0 < key || (k0 == key && 0 < j)) + (int)(k1 < key || (k1 == key && 1 < j)) +
-                                 (int)(k2 < key || (k2 == key && 2 < j)) + (int)(k3 < key || (k3 == key && 3 < j));
-                const int nh = (int)(k0 != 0x7fffffff) + (int)(k1 != 0x7fffffff) + (int)(k2 != 0x7fffffff) + (int)(k3 != 0x7fffffff);
-                if (nh > 0) {
-                    // nearest child next; the others to the stack, farthest at the bottom — each lane writes its own entry
-                    if (key != 0x7fffffff && rank > 0) st_store(sp + (nh - 1 - rank), ref);
-                    const int mine = (rank == 0) ? ref : 0;      // a child ref is never 0 (node 0 is the root), and rank 0 is a hit child when nh > 0
-                    cur = quad_bcast<0>(mine) | quad_bcast<1>(mine) | quad_bcast<2>(mine) | quad_bcast<3>(mine);
-                    sp += nh - 1;
-                } else if (sp == 0) {
-                    cur = kDone;
-                } else {
-                    sp--;
-                    cur = st_load(sp);
-                }
-            } else {
-                // ---- leaf: lane j = triangle j (Triangle::hit + the reference's leaf box: tri_test), then the best of the quad ----
-                const int code = ~cur, first = code >> 3, cnt = code & 7;
-                if (j < cnt) tri_test(sc, first + j, org, dir, inv, degenerate, bestT, bestPrim);
-#define PT_QBEST(I) { const float ti = __int_as_float(quad_bcast<I>(__float_as_int(bestT))); const int pi = quad_bcast<I>(bestPrim); \
-                      if (ti < bestT || (ti == bestT && pi > bestPrim)) { bestT = ti; bestPrim = pi; } }
-                PT_QBEST(0) PT_QBEST(1) PT_QBEST(2) PT_QBEST(3)
-#undef PT_QBEST
-                if (bestPrim >= 0 && bestT < stopBelow) { cur = kDone; sp = 0; }          // shadow ray: any occluder in front of the light will do
-                else if (cnt > 4) cur = ~(((first + 4) << 3) | (cnt - 4));
-                else if (sp == 0) cur = kDone;
-                else { sp--; cur = st_load(sp); }
-            }
-            if (cur == kDone) {
-                if (j == 0) {
-                    // spheres, in order, against the triangles' closest t (CudaUtil.cuh:137-145)
-                    for (int s = 0; s < sc.n_spheres; s++) {
-                        const float4 c = sc.spheres[4 * s];
-                        float root;
-                        if (sphere_root(f3(c.x, c.y, c.z), c.w, org, dir, bestT, root)) { bestT = root; bestPrim = sc.n_tris + s; }
-                    }
-                    if (PUBLISH) __hip_atomic_store((unsigned long long*)&b.hit[0][hs], (unsigned long long)__float_as_uint(bestT) | ((unsigned long long)(uint32_t)bestPrim << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else st_s(&b.hit[0][hs], make_float2(bestT, __int_as_float(bestPrim)));
-                }
-                alive = false;
-            }
-        }
-    }
-}
-
 // STAT: a diagnostic build that also counts trips and the lanes they serve (pt_last_counters; PTAMD_TSTAT=1).
-template <int MODE, bool PUBLISH = false, bool QUAD = false>      // QUAD: a wave that is down to <= 16 rays after the queue has run dry finishes them four lanes per ray (quad_tail);  PUBLISH: hits are stored device-coherently (wf_shade PHASE 1 reads them while this kernel drains);  MODE: 0 production, 1 trip counters + histograms + timeline (PTAMD_TSTAT=1), 2 timeline only (PTAMD_TSTAT=2), 3 trip counters + section clocks, no per-step atomics (PTAMD_TSTAT=3)
+template <int MODE, bool PUBLISH = false>      // PUBLISH: hits are stored device-coherently (wf_shade PHASE 1 reads them while this kernel drains);  MODE: 0 production, 1 trip counters + histograms + timeline (PTAMD_TSTAT=1), 2 timeline only (PTAMD_TSTAT=2), 3 trip counters + section clocks, no per-step atomics (PTAMD_TSTAT=3)
 __global__ __launch_bounds__(256, TRACE_WAVES)
 void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift, int triTrig, int refillMin,
               int topWant, unsigned long long* stat, int statLaunch)
@@ -279,7 +160,6 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
     unsigned long long stClk[5] = {0, 0, 0, 0, 0}, stMark = 0;      // STAT: shader clocks in refill / vote + budget / node step / triangle step / ray epilogue
     unsigned long long stNodeTrips = 0, stNodeLanes = 0, stTriTrips = 0, stTriLanes = 0, stRefills = 0, stRefillLanes = 0, stNoRayLanes = 0, stRays = 0;
     __shared__ int lds_stack[4][kWfLdsStack * 64];
-    [[maybe_unused]] __shared__ int lds_quad[QUAD ? 4 : 1][16];
     // one queue index space: [0, nPath) path rays, then the shadow rays of kind 1, then those of kind 2
     const uint32_t nPath = b.cnt[slot].nRays[0][0];
     const uint32_t nKind1 = nPath + b.cnt[slot].nRays[1][0];
@@ -414,15 +294,6 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
             }
         }
         PT_STCLK(0)
-        if (QUAD && exhausted) {
-            const int nLive = __builtin_popcountll(__ballot(hasRay));
-            if (nLive == 0) break;
-            if (nLive <= 16) {
-                quad_tail<PUBLISH>(sc, b, &lds_stack[threadIdx.x >> 6][0], b.ovf + (blockIdx.x * 256 + (threadIdx.x & ~63)), ovfStride, &lds_quad[threadIdx.x >> 6][0],
-                                   hasRay, org, dir, inv, bestT, cscale, stopBelow, bestPrim, cur, sp, pend, degenerate, hs);
-                break;
-            }
-        }
         if (__ballot(hasRay) == 0ull) { if (exhausted) break; else continue; }
         if (hasRay) {
             // Only one code path runs per trip: a node step or ONE triangle test per lane (the vote is below).
@@ -894,7 +765,6 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     // two per CU; other shapes re-measured after that change: 256 threads -4 %, 384 / 768 -13 %, 1024 -8 %, 3 waves/SIMD -9...-13 %
     // (profiles/r02_experiments/r02_t16_shade_shapes_after_noslp.log)
     static const int shadeThreads = (getenv("PTAMD_ST") && atoi(getenv("PTAMD_ST")) >= 64 && atoi(getenv("PTAMD_ST")) <= kShadeThreads) ? (atoi(getenv("PTAMD_ST")) & ~63) : 512;
-    static const bool quadTail = getenv("PTAMD_QUAD") ? atoi(getenv("PTAMD_QUAD")) != 0 : false;      // wf_trace: the last <= 16 rays of a wave four lanes per ray (quad_tail)
     static const int earlyPrio = getenv("PTAMD_EPRIO") ? atoi(getenv("PTAMD_EPRIO")) : 0;          // issue priority of the traversal waves while wf_shade's early phase runs beside them
     static const bool pubOnly = getenv("PTAMD_EPUB") && atoi(getenv("PTAMD_EPUB")) != 0;          // A/B: device-scope hit stores and marks, but no early phase
     static const int earlyThreads = (getenv("PTAMD_EST") && atoi(getenv("PTAMD_EST")) >= 64 && atoi(getenv("PTAMD_EST")) <= kShadeThreads) ? (atoi(getenv("PTAMD_EST")) & ~63) : 256;
@@ -932,12 +802,9 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
             }
             if (traceStat && traceStatClk) hipLaunchKernelGGL(wf_trace<3>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
             else if (traceStat && traceStatFull) hipLaunchKernelGGL(wf_trace<1>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
-#define PT_TRACE(M, P, Q, ST, SL) hipLaunchKernelGGL((wf_trace<M, P, Q>), dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, ST, SL)
-            else if (traceStat) { if (quadTail) PT_TRACE(2, false, true, traceStat, it < 2700 ? it : 2699); else PT_TRACE(2, false, false, traceStat, it < 2700 ? it : 2699); }
-            else if (early || pubOnly) { if (quadTail) PT_TRACE(0, true, true, (unsigned long long*)nullptr, earlyPrio); else PT_TRACE(0, true, false, (unsigned long long*)nullptr, earlyPrio); }
-            else if (quadTail) PT_TRACE(0, false, true, (unsigned long long*)nullptr, 0);
-            else PT_TRACE(0, false, false, (unsigned long long*)nullptr, 0);
-#undef PT_TRACE
+            else if (traceStat) hipLaunchKernelGGL(wf_trace<2>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
+            else if (early || pubOnly) hipLaunchKernelGGL((wf_trace<0, true>), dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, earlyPrio);
+            else hipLaunchKernelGGL(wf_trace<0>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, 0);
             if (timed) (void)hipEventRecord(trace_ev[3 * it + 1], stream);
             const dim3 sg((liveBound + shadeThreads - 1) / shadeThreads), sb(shadeThreads);
             const bool twoRounds = shadeRounds >= 0 ? (shadeRounds != 0) : (liveBound < trStreams);
