@@ -733,6 +733,47 @@ static void carve(char* p, size_t nStreams, int traceBlocks, ptd::WfBuf& b)
 
 const float* ptk_wf_staging(void* work) { return (const float*)work; }
 
+// Scheduling constants of the pipeline, read from the environment ONCE per process (tuning and A/B sweeps only — none of them can
+// change a result).  Defaults are the measured optima on MI355X.
+struct WfTuning {
+    int chunkShift;      // PTAMD_CS   chunk  = clamp(n >> CS, 16, kWfChunk) ray ids per queue access
+    int guideShift;      // PTAMD_GS   guided = the chunk shrinks to (rays left in the shard) >> GS
+    int budgetShift;     // PTAMD_BS   node budget = clamp(n >> BS, BM, 1024) steps per launch
+    int budgetMin;       // PTAMD_BM
+    int refillMin;       // PTAMD_RF   idle lanes that trigger a refill
+    int triTrig;         // PTAMD_TT   parked leaves that force a triangle trip (64 = only when blocked rays outnumber walking ones)
+    int topNodes;        // PTAMD_TOP  quad nodes staged in LDS (TRACE_TOP_NODES builds only)
+    // wf_shade: 4 waves/SIMD (126 VGPRs, nothing spilled since the library is built without the SLP vectoriser) in 512-thread workgroups =
+    // two per CU; other shapes: 256 threads -4 %, 384 / 768 -13 %, 1024 -8 %, 3 waves/SIMD -9...-13 % (r02_t16_shade_shapes_after_noslp.log)
+    int shadeWaves;      // PTAMD_SW
+    int shadeThreads;    // PTAMD_ST
+    // wf_shade: may a stream whose path has just ended start its next sample in the same step (a second trip through the bounce code)?
+    // It saves one iteration per sample but doubles the step's dependent chain: shadeRounds 0 / 1 forces it (pt_set_shade_rounds,
+    // PTAMD_TR), -1 switches at trStreams live streams.  The result does not depend on it (pt_stream.h: shade_step_t).
+    uint32_t trStreams;  // PTAMD_TRS
+    int earlyThreads;    // PTAMD_EST  threads per workgroup of wf_shade's early phase (64: one free wave slot is enough; 512 / 256 / 128 / 64 -> 0.488 / 0.481 / 0.473 / 0.472 s for an 8-way rank)
+    int earlyPrio;       // PTAMD_EPRIO issue priority of the traversal waves while the early phase runs beside them (no effect measured)
+    bool pubOnly;        // PTAMD_EPUB  A/B: device-scope hit stores and marks, but no early phase
+    int traceStat;       // PTAMD_TSTAT 1 trip counters + histograms (slower build), 2 timeline only (production code path), 3 trip counters + section clocks
+};
+static const WfTuning& wf_tuning()
+{
+    static const WfTuning t = [] {
+        auto num = [](const char* name, long long def) -> long long { const char* v = getenv(name); return v ? atoll(v) : def; };
+        auto threads = [&](const char* name, int def) { const long long v = num(name, def); return (v >= 64 && v <= ptd::kShadeThreads) ? (int)(v & ~63LL) : def; };
+        WfTuning w;
+        w.chunkShift = (int)num("PTAMD_CS", 12); w.guideShift = (int)num("PTAMD_GS", 9);
+        w.budgetShift = (int)num("PTAMD_BS", 14); w.budgetMin = (int)num("PTAMD_BM", ptd::kWfBudget);
+        w.refillMin = (int)num("PTAMD_RF", ptd::kWfRefill); w.triTrig = (int)num("PTAMD_TT", 64); w.topNodes = (int)num("PTAMD_TOP", ptd::kTopNodes);
+        w.shadeWaves = (int)num("PTAMD_SW", 4); w.shadeThreads = threads("PTAMD_ST", 512);
+        w.trStreams = (uint32_t)num("PTAMD_TRS", 4000000);
+        w.earlyThreads = threads("PTAMD_EST", 64); w.earlyPrio = (int)num("PTAMD_EPRIO", 0); w.pubOnly = num("PTAMD_EPUB", 0) != 0;
+        w.traceStat = (int)num("PTAMD_TSTAT", 0);
+        return w;
+    }();
+    return t;
+}
+
 // One cohort's pipeline on its own stream.  Blocks the calling host thread until the cohort has
 // drained (it polls the live-stream count every 16..64 iterations).
 static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::DevCamera* cam, ptd::DevParams prm,
@@ -752,33 +793,11 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     // every sample needs at most max_bounce + (max_refract + 2) bounces, +1 iteration to retire
     // (time-sliced rays add iterations; 64x is far beyond anything a finite tree can need)
     const long long hardCap = ((long long)prm.spp_per_pass * (prm.max_bounce + prm.max_refract + 3) + 8) * 64;
-    // Scheduling constants of wf_trace.  Each has an environment override used for the sweeps recorded in
-    // DESIGN.md section 5.4 (tuning only — none of them can change a result):
-    //   PTAMD_CS  chunk  = clamp(n >> CS, 16, kWfChunk) ray ids per queue access        (default 12)
-    //   PTAMD_GS  guided = chunk shrinks to (rays left in the shard) >> GS              (default 9)
-    //   PTAMD_BS / PTAMD_BM  node budget = clamp(n >> BS, BM, 1024) steps per launch    (default 14 / 256)
-    static const int guideShift = getenv("PTAMD_GS") ? atoi(getenv("PTAMD_GS")) : 9;
-    static const int budgetShift = getenv("PTAMD_BS") ? atoi(getenv("PTAMD_BS")) : 14;
-    static const int budgetMin = getenv("PTAMD_BM") ? atoi(getenv("PTAMD_BM")) : kWfBudget;
-    static const int shadeWaves = getenv("PTAMD_SW") ? atoi(getenv("PTAMD_SW")) : 4;
-    // wf_shade: 4 waves/SIMD (126 VGPRs, nothing spilled since the library is built without the SLP vectoriser) in 512-thread workgroups =
-    // two per CU; other shapes re-measured after that change: 256 threads -4 %, 384 / 768 -13 %, 1024 -8 %, 3 waves/SIMD -9...-13 %
-    // (profiles/r02_experiments/r02_t16_shade_shapes_after_noslp.log)
-    static const int shadeThreads = (getenv("PTAMD_ST") && atoi(getenv("PTAMD_ST")) >= 64 && atoi(getenv("PTAMD_ST")) <= kShadeThreads) ? (atoi(getenv("PTAMD_ST")) & ~63) : 512;
-    static const int earlyPrio = getenv("PTAMD_EPRIO") ? atoi(getenv("PTAMD_EPRIO")) : 0;          // issue priority of the traversal waves while wf_shade's early phase runs beside them
-    static const bool pubOnly = getenv("PTAMD_EPUB") && atoi(getenv("PTAMD_EPUB")) != 0;          // A/B: device-scope hit stores and marks, but no early phase
-    static const int earlyThreads = (getenv("PTAMD_EST") && atoi(getenv("PTAMD_EST")) >= 64 && atoi(getenv("PTAMD_EST")) <= kShadeThreads) ? (atoi(getenv("PTAMD_EST")) & ~63) : 256;
-    static const int refillMin = getenv("PTAMD_RF") ? atoi(getenv("PTAMD_RF")) : kWfRefill;     // idle lanes that trigger a refill
-    static const int triTrig = getenv("PTAMD_TT") ? atoi(getenv("PTAMD_TT")) : 64;
-    static const int chunkShift = getenv("PTAMD_CS") ? atoi(getenv("PTAMD_CS")) : 12;
-    static const int topNodes = getenv("PTAMD_TOP") ? atoi(getenv("PTAMD_TOP")) : kTopNodes;      // quad nodes staged in LDS (0 = none)
-    // wf_shade: may a stream whose path has just ended start its next sample in the same step (a second trip through the bounce code)?
-    // It saves one iteration per sample (bounces - 1 instead of bounces) but doubles the step's dependent chain for every wave.
-    // With many streams in flight the chain is what bounds wf_shade, with few the iteration count: shadeRounds 0 / 1 forces it
-    // (pt_set_shade_rounds, PTAMD_TR), -1 switches at PTAMD_TRS live streams.  The result does not depend on it (pt_stream.h: shade_step_t).
-    static const uint32_t trStreams = getenv("PTAMD_TRS") ? (uint32_t)atoll(getenv("PTAMD_TRS")) : 4000000u;
-    static const bool traceStatClk = getenv("PTAMD_TSTAT") && atoi(getenv("PTAMD_TSTAT")) == 3;      // 3: trip counters + section clocks, no histograms
-    static const bool traceStatFull = getenv("PTAMD_TSTAT") && atoi(getenv("PTAMD_TSTAT")) == 1;      // 1: trip counters too (slower build); 2: timeline only
+    const WfTuning& tn = wf_tuning();
+    const int guideShift = tn.guideShift, budgetShift = tn.budgetShift, budgetMin = tn.budgetMin, shadeWaves = tn.shadeWaves, shadeThreads = tn.shadeThreads;
+    const int earlyPrio = tn.earlyPrio, earlyThreads = tn.earlyThreads, refillMin = tn.refillMin, triTrig = tn.triTrig, chunkShift = tn.chunkShift, topNodes = tn.topNodes;
+    const bool pubOnly = tn.pubOnly, traceStatClk = tn.traceStat == 3, traceStatFull = tn.traceStat == 1;
+    const uint32_t trStreams = tn.trStreams;
     int it = 0;
     int poll = 16;
     // streams only ever retire, so the live count of the last poll bounds every later one: the shade grid
