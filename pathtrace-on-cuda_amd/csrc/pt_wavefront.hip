@@ -526,7 +526,10 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
     uint32_t sid = 0, resume = 0;      // resume: the queued rays are suspended traversals (wf_trace then reads their records)
     bool step = have;
     if (have) {
-        sid = ld_s(&b.active[listIn][idx]);
+        // While no stream has retired yet (more than half of a render's iterations) every stream is alive, so list position idx can
+        // simply take stream idx: one dependent fetch level less for the whole step (the list itself is in stream order only inside the
+        // blocks that appended to it; any one-to-one assignment of streams to lanes gives the same result).
+        sid = (nIn == (uint32_t)prm.n_units * 64u) ? idx : ld_s(&b.active[listIn][idx]);
         if (PHASE == 2) {
             const uint32_t r = b.res[idx];
             if (r & R_DONE) {      // shaded by phase 1: only the appends are left
