@@ -247,6 +247,9 @@ PT_API int  pt_dbg_raycast(PtScene* s, const float* rays8, int32_t n, float* out
 PT_API int  pt_dbg_bxdf(int32_t device, int32_t lobe, const float* in28, int32_t n, float* out12);
 PT_API int  pt_dbg_rng(int32_t device, uint64_t seed, int32_t n, uint32_t* raw_out, float* uniform_out);
 PT_API int  pt_dbg_math(int32_t device, const float* in, int32_t n, float* out8);
+/* The sin / cos pair of the BxDF samplers (pathtrace-on-cuda_amd/csrc/pt_sincos.h; angles in [0, 2 pi], include/Bxdf.cuh:23-41,140-150):
+ * out2 = sin cos per input, to be compared with (float)sin((double)x), (float)cos((double)x) bit for bit. */
+PT_API int  pt_dbg_sincos(int32_t device, const float* in, int32_t n, float* out2);
 /* The per-ray set-up of the traversal kernel (csrc/pt_trace.h: ray_setup) on n directions (3 floats each): out5 = the reference's
  * Normalize(inv(dir)) (include/CudaUtil.cuh:60-63, :70) x, y, z | the kernel's cull scale | 1.0 for a degenerate direction; the
  * test compares it with IEEE arithmetic bit for bit. */

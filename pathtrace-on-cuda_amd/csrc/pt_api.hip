@@ -26,6 +26,7 @@ hipError_t ptk_dbg_raycast(const ptd::DevScene*, const float*, int, float*, int*
 hipError_t ptk_dbg_bxdf(int, const float*, int, float*, hipStream_t);
 hipError_t ptk_dbg_rng(unsigned long long, int, uint32_t*, float*, hipStream_t);
 hipError_t ptk_dbg_math(const float*, int, float*, hipStream_t);
+hipError_t ptk_dbg_sincos(const float*, int, float*, hipStream_t);
 hipError_t ptk_dbg_ray_setup(const float*, int, float*, hipStream_t);
 hipError_t ptk_dbg_pixel_dir(const ptd::DevCamera*, const int*, int, float*, hipStream_t);
 hipError_t ptk_dbg_nee(const ptd::DevScene*, const float*, int, float*, hipStream_t);
@@ -638,6 +639,12 @@ int pt_dbg_math(int32_t device, const float* in, int32_t n, float* out8)
     if (!in || !out8 || n < 0) { pt_set_error("pt_dbg_math: bad argument"); return PT_ERR_INVALID; }
     return with_buffers(device, in, (size_t)n * 4, out8, (size_t)n * 8 * 4, nullptr, 0,
                         [&](void* i, void* o, void*) { return ptk_dbg_math((const float*)i, n, (float*)o, nullptr); });
+}
+int pt_dbg_sincos(int32_t device, const float* in, int32_t n, float* out2)
+{
+    if (!in || !out2 || n < 0) { pt_set_error("pt_dbg_sincos: bad argument"); return PT_ERR_INVALID; }
+    return with_buffers(device, in, (size_t)n * 4, out2, (size_t)n * 2 * 4, nullptr, 0,
+                        [&](void* i, void* o, void*) { return ptk_dbg_sincos((const float*)i, n, (float*)o, nullptr); });
 }
 
 }  // extern "C"

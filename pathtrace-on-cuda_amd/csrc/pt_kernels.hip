@@ -308,6 +308,16 @@ __global__ void dbg_math(const float* __restrict__ in, int n, float* __restrict_
     o[7] = length(f3(x, x + 1.f, x + 2.f));
 }
 
+// the samplers' sin / cos pair (pt_math.h: cr_sincos, angles in [0, 2 pi]): out2 = sin cos
+__global__ void dbg_sincos(const float* __restrict__ in, int n, float* __restrict__ out2)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s, c;
+    cr_sincos(in[i], s, c);
+    out2[2 * (size_t)i] = s; out2[2 * (size_t)i + 1] = c;
+}
+
 }  // namespace ptd
 
 // ---------------------------------------------------------------------------------------
@@ -367,6 +377,12 @@ hipError_t ptk_dbg_math(const float* in, int n, float* out8, hipStream_t stream)
 {
     const int nb = (n + 255) / 256;
     if (nb > 0) hipLaunchKernelGGL(ptd::dbg_math, dim3(nb), dim3(256), 0, stream, in, n, out8);
+    return hipGetLastError();
+}
+hipError_t ptk_dbg_sincos(const float* in, int n, float* out2, hipStream_t stream)
+{
+    const int nb = (n + 255) / 256;
+    if (nb > 0) hipLaunchKernelGGL(ptd::dbg_sincos, dim3(nb), dim3(256), 0, stream, in, n, out2);
     return hipGetLastError();
 }
 

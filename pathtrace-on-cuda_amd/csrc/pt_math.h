@@ -15,6 +15,8 @@
 #include <stdint.h>
 
 #define PT_DEV __device__ __forceinline__
+#define PT_SC_FN __device__ __forceinline__
+#include "pt_sincos.h"
 
 namespace ptd {
 
@@ -67,9 +69,23 @@ PT_DEV f3 refract(const f3& w, const f3& n, float inv_eta) {
 PT_DEV float cr_sin(float x) { return (float)::sin((double)x); }
 PT_DEV float cr_cos(float x) { return (float)::cos((double)x); }
 PT_DEV float cr_atan(float x) { return (float)::atan((double)x); }
-// sin and cos of the same angle share one argument reduction (OCML's sincos returns exactly what its sin and cos return: the
-// BxDF tables of tests/test_gpu_parity.py compare every sample with the oracle bit for bit); half the fp64 work of two calls.
-PT_DEV void cr_sincos(float x, float& s, float& c) { double ds, dc; ::sincos((double)x, &ds, &dc); s = (float)ds; c = (float)dc; }
+// sin and cos of a sampler's angle (always in [0, 2 pi]: phi = 2 pi u, theta = atan(.) >= 0), correctly rounded to float: pt_sincos.h —
+// fp64, reduced to what that domain needs (≈50 instead of OCML sincos's 157 VALU instructions a pair) and checked on the host against
+// the oracle's definition for EVERY float of the domain (tools/sincos_check.c: zero mismatches).  PT_OCML_SINCOS = 1 builds rounds 1-2's
+// call of OCML's general double sincos instead (A/B).
+#ifndef PT_OCML_SINCOS
+#define PT_OCML_SINCOS 0
+#endif
+PT_DEV void cr_sincos(float x, float& s, float& c)
+{
+    double ds, dc;
+#if PT_OCML_SINCOS
+    ::sincos((double)x, &ds, &dc);
+#else
+    pt_sincos_0_2pi((double)x, &ds, &dc);
+#endif
+    s = (float)ds; c = (float)dc;
+}
 // x^5 for x in [1e-4, 0.999]: two exact-ish fp64 products (error 2^-52) rounded once.
 PT_DEV float cr_pow5(float x) { double d = (double)x; double d2 = d * d; return (float)((d2 * d2) * d); }
 // x^2 rounded once == the float product.

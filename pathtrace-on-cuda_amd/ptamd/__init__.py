@@ -87,6 +87,7 @@ API = [
     ("pt_dbg_bxdf", C.c_int, [C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     ("pt_dbg_rng", C.c_int, [C.c_int32, C.c_uint64, C.c_int32, _P, _P]),
     ("pt_dbg_math", C.c_int, [C.c_int32, _P, C.c_int32, _P]),
+    ("pt_dbg_sincos", C.c_int, [C.c_int32, _P, C.c_int32, _P]),
     ("pt_dbg_ray_setup", C.c_int, [C.c_int32, _P, C.c_int32, _P]),
     ("pt_dbg_pixel_dir", C.c_int, [C.c_int32, C.POINTER(PtCamera), _P, C.c_int32, _P]),
     ("pt_dbg_nee", C.c_int, [_P, _P, C.c_int32, _P]),
@@ -467,6 +468,14 @@ def dbg_ray_setup(dirs, device=0):
     d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
     out = np.zeros((d.shape[0], 5), np.float32)
     _check(lib().pt_dbg_ray_setup(device, _ptr(d), d.shape[0], _ptr(out)), "pt_dbg_ray_setup")
+    return out
+
+
+def dbg_sincos(x, device=0):
+    """(n, 2) float32: sin, cos of the samplers' device function (angles in [0, 2 pi])."""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros((x.shape[0], 2), np.float32)
+    _check(lib().pt_dbg_sincos(device, _ptr(x), x.shape[0], _ptr(out)), "pt_dbg_sincos")
     return out
 
 

@@ -74,6 +74,28 @@ def test_device_arithmetic_is_ieee_and_correctly_rounded():
         assert bad <= 1, f"column {col}: {bad} results not correctly rounded"
 
 
+def test_sampler_sincos_is_the_oracles_on_its_whole_domain():
+    """The samplers' sin / cos (csrc/pt_sincos.h, angles in [0, 2 pi]) against the oracle's definition — glibc double sin / cos rounded once
+    to float — on 8 M floats: dense random angles, every float around the quadrant boundaries, tiny angles, the largest phi.  The host
+    build of the same function is checked on EVERY float of the domain (tools/sincos_check.c, tests/test_host.py): zero mismatches
+    there, so zero are allowed here."""
+    rs = np.random.RandomState(5)
+    parts = [rs.uniform(0, 6.283186, 6000000), 10.0 ** rs.uniform(-30, 0.8, 500000)]
+    for k in range(5):      # every float within 2^17 ulps of k * pi / 2
+        c = np.float32(k * np.pi / 2)
+        b = np.array([c], np.float32).view(np.uint32)[0]
+        lo = max(int(b) - (1 << 17), 0)
+        parts.append(np.arange(lo, int(b) + (1 << 17), dtype=np.uint32).view(np.float32).astype(np.float64))
+    x = np.concatenate(parts).astype(np.float32)
+    x = x[(x >= 0) & (x <= np.float32(6.283186))]
+    x = np.concatenate([x, np.array([0.0, 6.283184, 6.283186, 1.5707964, 3.1415927], np.float32)])
+    out = ptamd.dbg_sincos(x)
+    x64 = x.astype(np.float64)
+    assert np.array_equal(bits(out[:, 0]), bits(np.sin(x64).astype(np.float32)))
+    assert np.array_equal(bits(out[:, 1]), bits(np.cos(x64).astype(np.float32)))
+    assert np.isnan(ptamd.dbg_sincos(np.array([np.nan], np.float32))).all()
+
+
 def test_ray_setup_matches_ieee_arithmetic():
     """wf_trace's per-ray set-up (pt_trace.h: ray_setup — the reference's Normalize(inv(dir)), its degenerate case and the clamp)
     bit for bit against IEEE arithmetic (numpy float32) on a million directions: unit vectors, components down to 1e-30, exact

@@ -137,3 +137,22 @@ def test_comm_single_rank_and_argument_checks(tmp_path):
             ptamd.Comm(rank=rank, world=world, unique_id=bytes(128))
     with pytest.raises(ptamd.PtError, match="timed out"):
         ptamd.Comm(rank=1, world=2, id_file=str(tmp_path / "never_written.id"), timeout_s=0)
+
+
+def test_sampler_sincos_matches_glibc_on_every_float_of_its_domain(tmp_path):
+    """csrc/pt_sincos.h (the device's sin / cos for the BxDF samplers) compiled for the host and compared with the oracle's definition,
+    (float)sin((double)x) / (float)cos((double)x) of glibc, for EVERY float in [0, 6.283186]: 1,086,918,621 values, zero mismatches
+    (tools/sincos_check.c; a few seconds on 8 threads)."""
+    import json
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "sincos_check")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-I", os.path.join(root, "pathtrace-on-cuda_amd", "csrc"),
+                    os.path.join(root, "tools", "sincos_check.c"), "-o", exe, "-lm", "-lpthread"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    d = json.loads(r.stdout)
+    assert r.returncode == 0 and d["floats_checked"] > 1_000_000_000
+    assert d["sin_mismatches"] == 0 and d["cos_mismatches"] == 0 and d["nan_in_nan_out"]
