@@ -21,6 +21,8 @@
 // keeps walking, so both kinds of trip run fuller.  Rays that exceed a node budget are suspended
 // and resumed by the next launch (time slicing).  Shadow rays stop at the first hit that is
 // provably in front of the sampled light point (result-neutral, see wf_trace).
+// For small renders (one rank of an 8-way tile split, a single full-frame pass) the shade step starts on a second stream beside
+// the draining traversal kernel ("early shade", wf_shade PHASE 1 / 2): the launch tail of wf_trace is then not idle time.
 //
 // Per-stream arithmetic — order of random draws, every float operation — is exactly that of
 // render_units / the reference's GetColor_iter, so images are bit-identical across modes.
@@ -504,7 +506,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
 //   PHASE 2 (rest)   runs after both have finished: shades the streams phase 1 skipped and does ALL the appends, in list order — so the
 //                    live list and the ray queues keep stream order exactly as with one launch.
 // A stream goes through the same shade_step either way: result-neutral.
-enum : uint32_t { R_ALIVE = 1, R_EMIT0 = 2, R_EMIT1 = 4, R_EMIT2 = 8, R_RESUME = 16, R_DONE = 128 };
+enum : uint32_t { R_ALIVE = 1, R_EMIT0 = 2, R_EMIT1 = 4, R_EMIT2 = 8, R_DONE = 128 };      // res[]: what phase 1 did with a list position
 
 PT_DEV float2 load_hit_coherent(const float2* p)
 {
