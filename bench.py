@@ -125,6 +125,17 @@ def cpu_baseline(cfg, nodes, tris, ncores):
     return out
 
 
+def render_calls(steps, passes_per_call, first_pass=0):
+    """The K timed steps as render calls of at most the config's own pass count (PathTracer::Render keeps NUM_MULTI_SAMPLE passes in
+    flight, no more): [(first pass index, passes)], e.g. 20 steps of an 8-pass config -> 8 + 8 + 4."""
+    calls, done = [], 0
+    while done < steps:
+        n = min(passes_per_call, steps - done)
+        calls.append((first_pass + done, n))
+        done += n
+    return calls
+
+
 def load_pmc(config):
     """Per-sample PMC sums of this config's kernels (tools/pmc_summary.py -> profiles/r02_pmc_config<C>.json), or None."""
     for rnd in ("r03", "r02"):
@@ -203,12 +214,7 @@ def main():
     # The K timed steps go out in render calls of at most the config's own pass count (PathTracer::Render keeps NUM_MULTI_SAMPLE
     # passes in flight, no more): --steps 20 on configs[2] = 8 + 8 + 4.  One work buffer serves all calls (they run one after the
     # other); every call has its own tile buffer, summed on the device into one before the single gather.
-    per_call = cfg["passes"] if not args.all_in_flight else args.steps
-    calls, done = [], 0
-    while done < args.steps:
-        n = min(per_call, args.steps - done)
-        calls.append((args.warmup + done, n))
-        done += n
+    calls = render_calls(args.steps, args.steps if args.all_in_flight else cfg["passes"], args.warmup)
     big = max(n for _, n in calls)
     n_warm = min(args.warmup, cfg["passes"])
     shared_work = torch.zeros(ptamd.work_bytes(cam, params(0, max(big, n_warm))) // 4, dtype=torch.float32, device=dev)

@@ -156,3 +156,16 @@ def test_sampler_sincos_matches_glibc_on_every_float_of_its_domain(tmp_path):
     d = json.loads(r.stdout)
     assert r.returncode == 0 and d["floats_checked"] > 1_000_000_000
     assert d["sin_mismatches"] == 0 and d["cos_mismatches"] == 0 and d["nan_in_nan_out"]
+
+
+def test_bench_times_render_calls_of_the_configs_own_shape():
+    """bench.py submits the K timed steps in render calls of at most the config's pass count (configs[2]: 8): --steps 20 = 8 + 8 + 4."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    assert [n for _, n in bench.render_calls(20, 8, 5)] == [8, 8, 4]
+    assert bench.render_calls(20, 8, 5) == [(5, 8), (13, 8), (21, 4)]
+    assert bench.render_calls(8, 8, 1) == [(1, 8)] and bench.render_calls(3, 8) == [(0, 3)] and bench.render_calls(20, 20) == [(0, 20)]
+    for c in bench.CONFIGS.values():
+        assert c["passes"] == 8
