@@ -148,3 +148,38 @@ def test_cli_render_matches_library_and_oracle(tmp_path):
     ref, _ = O.Scene(nodes.tobytes(), tris, glass).render(O.make_camera(W, H), O.make_params(W, H, passes, spp, max_bounce=12), 8)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
     assert np.array_equal(_read_png(str(tmp_path / "result.png")), O.tonemap(ref, passes))
+
+
+RENDER_MGPU = os.path.join(ptamd.PKG_ROOT, "render_mgpu")
+
+
+def test_render_mgpu_builds_and_fails_loudly_without_a_gpu(tmp_path):
+    """integration/render_mgpu.cpp — INTEGRATION.md's one-process-per-GPU C++ program — is a compiled artefact of the package Makefile."""
+    assert os.path.exists(RENDER_MGPU)
+    r = subprocess.run([RENDER_MGPU, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "usage: render_mgpu" in r.stdout
+    assert subprocess.run([RENDER_MGPU, "--bogus"], capture_output=True).returncode == 2
+    assert subprocess.run([RENDER_MGPU, "--rank", "3", "--world", "2"], capture_output=True).returncode == 2
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([RENDER_MGPU, "--size", "64x48", "--passes", "1", "--spp", "1", "--scene", "0"], capture_output=True, text=True, cwd=tmp_path)
+        assert r.returncode == 99 and "pt_scene_create" in r.stderr          # the reference's convention: message, exit(99)
+
+
+@pytest.mark.gpu
+def test_render_mgpu_world1_matches_library(tmp_path):
+    """The C++ tile-split program with one rank (no RCCL involved): tiles -> pt_gather_frame -> frame, bit-identical to pt_render, and the PNG it
+    writes is pt_tonemap_u8 of that frame."""
+    W, H, passes, spp = 160, 96, 2, 4
+    raw = tmp_path / "frame.f32"
+    r = subprocess.run([RENDER_MGPU, "--size", f"{W}x{H}", "--passes", str(passes), "--spp", str(spp), "--scene", "1", "--lat-lon", "16",
+                        "--out", str(tmp_path / "o.png"), "--raw", str(raw), "--id-file", str(tmp_path / "job.id"), "--job-tag", "77"],
+                       capture_output=True, text=True, cwd=tmp_path, timeout=600)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert "Export Success" in r.stdout and "rank 0 of 1" in r.stdout
+    assert not os.path.exists(tmp_path / "job.id")                              # world 1 never touches the rendezvous file
+    frame = np.fromfile(raw, np.float32).reshape(H, W, 3)
+    img = ptamd.Scene.from_prims(ptamd.gen_scene(1, 16)).render(ptamd.make_camera(W, H), ptamd.default_params(passes=passes, spp_per_pass=spp))
+    assert np.array_equal(frame.view(np.uint32), img.view(np.uint32))
+    from PIL import Image
+    assert np.array_equal(np.array(Image.open(tmp_path / "o.png")), ptamd.tonemap_u8(img, passes).reshape(H, W, 3))
