@@ -56,7 +56,7 @@ struct PtScene {
     ptd::DevScene dev{};
     void* d_nodes = nullptr; void* d_quad = nullptr; void* d_tri = nullptr; void* d_tripair = nullptr; void* d_leafbox = nullptr;
     void* d_surf = nullptr;
-    void* d_lights = nullptr; void* d_spheres = nullptr;
+    void* d_lights = nullptr; void* d_spheres = nullptr; void* d_core = nullptr;
     unsigned int* d_unit_counter = nullptr;
     void* d_counters = nullptr;
     int64_t bytes = 0;
@@ -212,6 +212,33 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
                                            e[0] <= 1e8f && e[1] <= 1e8f && e[2] <= 1e8f; };
     for (int i = 0; i < n_tris; i++) emitOk = emitOk && okE(tris[i].mat0.emittance);
     for (int i = 0; i < n_spheres; i++) emitOk = emitOk && okE(spheres[i].mat.emittance);
+    // ---- core box: the AABB of the scene's SMALL triangles (bounding-box diagonal under an eighth of the scene's).  A ray whose
+    // segment misses it can only meet the few big triangles, i.e. is short, and wf_shade queues such rays last (pt_stream.h:
+    // ray_is_short) so that the traversal kernel's launch tail consists of short rays.  Scheduling only — any box gives the same frame.
+    std::vector<float> core;
+    {
+        float smn[3] = {1e30f, 1e30f, 1e30f}, smx[3] = {-1e30f, -1e30f, -1e30f};
+        auto tribox = [&](const PtTriangle& t, float* mn, float* mx) {
+            for (int k = 0; k < 3; k++) { mn[k] = std::fmin(t.V0[k], std::fmin(t.V1[k], t.V2[k])); mx[k] = std::fmax(t.V0[k], std::fmax(t.V1[k], t.V2[k])); }
+        };
+        for (int i = 0; i < n_tris; i++) { float mn[3], mx[3]; tribox(tris[i], mn, mx); for (int k = 0; k < 3; k++) { smn[k] = std::fmin(smn[k], mn[k]); smx[k] = std::fmax(smx[k], mx[k]); } }
+        const float sd = std::sqrt((smx[0] - smn[0]) * (smx[0] - smn[0]) + (smx[1] - smn[1]) * (smx[1] - smn[1]) + (smx[2] - smn[2]) * (smx[2] - smn[2]));
+        float cmn[3] = {1e30f, 1e30f, 1e30f}, cmx[3] = {-1e30f, -1e30f, -1e30f};
+        int nSmall = 0;
+        for (int i = 0; i < n_tris; i++) {
+            float mn[3], mx[3]; tribox(tris[i], mn, mx);
+            const float dd = std::sqrt((mx[0] - mn[0]) * (mx[0] - mn[0]) + (mx[1] - mn[1]) * (mx[1] - mn[1]) + (mx[2] - mn[2]) * (mx[2] - mn[2]));
+            if (dd * 8.f < sd) { nSmall++; for (int k = 0; k < 3; k++) { cmn[k] = std::fmin(cmn[k], mn[k]); cmx[k] = std::fmax(cmx[k], mx[k]); } }
+        }
+        const double sv = (double)(smx[0] - smn[0]) * (smx[1] - smn[1]) * (smx[2] - smn[2]);
+        const double cv = nSmall ? (double)(cmx[0] - cmn[0]) * (cmx[1] - cmn[1]) * (cmx[2] - cmn[2]) : 0.0;
+        // worth it only if the small triangles are many (they are what makes rays long) and leave a good part of the scene free;
+        // PTAMD_CLASS=0 switches the queue order off (A/B)
+        if (nSmall >= 64 && std::isfinite(sv) && sv > 0.0 && cv <= 0.6 * sv && !(getenv("PTAMD_CLASS") && atoi(getenv("PTAMD_CLASS")) == 0)) {
+            for (int k = 0; k < 3; k++) { const float pad = 0.01f * (cmx[k] - cmn[k]) + 1e-4f * sd; cmn[k] -= pad; cmx[k] += pad; }
+            core = {cmn[0], cmn[1], cmn[2], cmx[0], cmx[1], cmx[2]};
+        }
+    }
     std::vector<float> sph((size_t)n_spheres * 16);
     for (int i = 0; i < n_spheres; i++) {
         const PtSphere& s = spheres[i];
@@ -233,7 +260,8 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
         (rc = upload(&sc->d_leafbox, accel.leafbox.data(), accel.leafbox.size() * 4, sc->bytes)) ||
         (rc = upload(&sc->d_surf, surf.data(), surf.size() * 4, sc->bytes)) ||
         (rc = upload(&sc->d_lights, lights.data(), lights.size() * 4, sc->bytes)) ||
-        (rc = upload(&sc->d_spheres, sph.data(), sph.size() * 4, sc->bytes))) {
+        (rc = upload(&sc->d_spheres, sph.data(), sph.size() * 4, sc->bytes)) ||
+        (!core.empty() && (rc = upload(&sc->d_core, core.data(), core.size() * 4, sc->bytes)))) {
         pt_scene_destroy(sc);
         return rc;
     }
@@ -266,6 +294,7 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     sc->dev.leafbox = (const float4*)sc->d_leafbox; sc->dev.surf = (const float4*)sc->d_surf;
     sc->dev.lights = (const float4*)sc->d_lights; sc->dev.spheres = (const float4*)sc->d_spheres;
     sc->dev.n_quad = accel.n_quad;
+    sc->dev.core = (const float*)sc->d_core;      // nullptr: no queue order by ray class
     sc->dev.nee_prune = (emitOk && !(getenv("PTAMD_PRUNE") && atoi(getenv("PTAMD_PRUNE")) == 0)) ? 1 : 0;      // PTAMD_PRUNE=0: A/B only
     sc->dev.n_nodes = n_wide; sc->dev.n_tris = n_tris; sc->dev.n_lights = n_lights; sc->dev.n_spheres = n_spheres;
     *out = sc;
@@ -276,7 +305,7 @@ void pt_scene_destroy(PtScene* s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void* p[] = {s->d_nodes, s->d_quad, s->d_tri, s->d_tripair, s->d_leafbox, s->d_surf, s->d_lights, s->d_spheres, s->d_unit_counter, s->d_counters};
+    void* p[] = {s->d_nodes, s->d_quad, s->d_tri, s->d_tripair, s->d_leafbox, s->d_surf, s->d_lights, s->d_spheres, s->d_core, s->d_unit_counter, s->d_counters};
     for (void* q : p) if (q) (void)hipFree(q);
     for (int i = 0; i < PtScene::kEvRing; i++) for (int j = 0; j < 2; j++) if (s->ev[i][j]) (void)hipEventDestroy(s->ev[i][j]);
     if (s->h_poll) (void)hipHostFree(s->h_poll);

@@ -113,13 +113,31 @@ PT_DEV float shadow_stop_t(const f3& o, float tmax)
     return (tmax - 1.0f) - __builtin_fmaxf(5e-4f, mag * 7.6293945e-6f);
 }
 
+// Queue order by ray class (round 3).  The launch tail of wf_trace is the longest ray still in flight when the queue runs dry
+// (~60-100 steps at ~3 us: ~0.3 ms whatever the launch size).  A ray whose segment misses the box around the scene's small triangles
+// (DevScene::core) can only meet the handful of big ones — <= 10 trips on the config scenes, 70 % of all rays — so such rays are
+// queued LAST: everything long has been started (and, in a large launch, finished) by the time the queue runs dry, and what is left
+// in flight is short.  Pure scheduling: the test may be as sloppy as it likes (approximate reciprocals), it decides no result.
+PT_DEV bool ray_is_short(const DevScene& sc, const f3& o, const f3& d, float tmax)
+{
+    if (sc.core == nullptr) return false;
+    const float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
+    const float ax = (sc.core[0] - o.x) * ix, bx = (sc.core[3] - o.x) * ix;
+    const float ay = (sc.core[1] - o.y) * iy, by = (sc.core[4] - o.y) * iy;
+    const float az = (sc.core[2] - o.z) * iz, bz = (sc.core[5] - o.z) * iz;
+    const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), 0.f));
+    const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), tmax));
+    return !(t0 <= t1);
+}
+
 struct WfCounters {      // one slot per iteration parity (3 rotating slots); every hot word on its own 128-B line
     uint32_t nActive, padA[31];
-    uint32_t nRays[kRayKinds][32];                 // [kind][0]: rays queued per kind
+    uint32_t nRays[kRayKinds][32];                 // [kind][0]: rays queued per kind from the front of its queue, [kind][16]: short rays queued from the back (kShortWord)
     uint32_t nSusp, padD[31];
     struct { uint32_t v, pad[31]; } head[16];     // sharded ray-queue heads, one 128-B line each
 };
 constexpr int kWfShards = 16;
+constexpr int kShortWord = 16;      // WfCounters::nRays[kind][kShortWord]: the kind's short-class rays
 constexpr int kWfSlotBytes = 128 * (2 + kRayKinds + 16);
 static_assert(sizeof(WfCounters) == kWfSlotBytes, "counter slot layout");
 
@@ -199,6 +217,7 @@ struct SState {
     f3 wb, lightP;                  // ... weight*brdfcos, sampled light point
     f3 pathO, pathD;                // path ray (traced if F_PATH)
     f3 shO, shD; float shTmax;      // shadow ray (traced if F_SHADOW)
+    uint32_t cls;                   // ray classes for the queue order (bit k: the ray of kind k is short, ray_is_short); scheduling only
     // The older closed sample (slot A: radiance, pending NEE term, shadow ray) never sits in registers across the
     // step: shade_step reads it where it is consumed and writes the new one where it is produced.
 };
@@ -273,6 +292,7 @@ PT_DEV bool bounce(const DevScene& sc, const DevParams& prm, int prim, float t, 
     // shadow ray: Ray(p, P - p), t_max = |P - p| + 1 (GetLightColor :152-157)
     st.shO = s.p; st.shD = wl; st.shTmax = length(toL) + 1.0f;
     if (!terminate) { st.pathO = nOrg; st.pathD = wi; }
+    st.cls = (st.cls & 4u) | ((!terminate && ray_is_short(sc, nOrg, wi, 3.0e38f)) ? 1u : 0u) | (ray_is_short(sc, st.shO, st.shD, st.shTmax) ? 2u : 0u);
     return terminate;
 }
 
@@ -346,6 +366,7 @@ PT_DEV bool shade_step_t(const DevScene& sc, const DevCamera& cam, const DevPara
                     st_s(&b.ray_o[2][sid], make_float4(st.shO.x, st.shO.y, st.shO.z, st.shTmax));
                     st_s(&b.ray_d[2][sid], make_float4(st.shD.x, st.shD.y, st.shD.z, shadow_stop_t(st.shO, st.shTmax)));
                     shA = true; neeA = neeCur; shCur = false; neeCur = false; closing = false;
+                    st.cls = (st.cls & ~4u) | ((st.cls & 2u) << 1);
                 }
                 prim = __float_as_int(h0.y); t = h0.x;
                 const float4 d0 = ld_s(dir0Ptr);
@@ -404,6 +425,7 @@ PT_DEV bool shade_step_t(const DevScene& sc, const DevCamera& cam, const DevPara
                 st_s(&b.ray_o[2][sid], make_float4(st.shO.x, st.shO.y, st.shO.z, st.shTmax));
                 st_s(&b.ray_d[2][sid], make_float4(st.shD.x, st.shD.y, st.shD.z, shadow_stop_t(st.shO, st.shTmax)));
                 shA = true; neeA = neeCur; shCur = false; neeCur = false; closing = false;
+                st.cls = (st.cls & ~4u) | ((st.cls & 2u) << 1);
             }
             prim = __float_as_int(h0.y); t = h0.x;
             const float4 d0 = ld_s(dir0Ptr);
@@ -456,7 +478,7 @@ PT_DEV void load_state(const WfBuf& b, uint32_t sid, SState& st)
     const float4 wq = ld_s(&b.weight[sid]), rq4 = ld_s(&b.rad[sid]);
     st.weight = f3(wq.x, wq.y, wq.z); st.radiance = f3(rq4.x, rq4.y, rq4.z);
     st.cosA = wq.w; st.denom = rq4.w;
-    st.pixelColor = f3(0.f, 0.f, 0.f); st.pixLoaded = false;
+    st.pixelColor = f3(0.f, 0.f, 0.f); st.pixLoaded = false; st.cls = 0u;
     // the current sample's rays and pending NEE term are fetched whatever the flags say (stale values are
     // never used): nearly every step has them, and waiting for the flags first only adds latency
     const float4 po = ld_s(&b.ray_o[0][sid]), pd = ld_s(&b.ray_d[0][sid]);

@@ -80,10 +80,12 @@ constexpr int kTopNodes = TRACE_TOP_NODES > 0 ? TRACE_TOP_NODES : 1;
 // counters on separate lines they no longer show.)
 // Must be called by every thread of the block.
 constexpr int kShadeThreads = 1024;      // largest wf_shade workgroup (the default runs 512-thread workgroups, two per CU: 4 waves/SIMD at 126 VGPRs)
-constexpr int kLists = 1 + kRayKinds;
+constexpr int kLists = 1 + 2 * kRayKinds;      // live streams + per ray kind a front list (through the core box / unknown) and a back list (short rays)
 template <int N>
-PT_DEV void block_append(const bool (&e)[N], const uint32_t (&id)[N], uint32_t* const (&c)[N], uint32_t* const (&l)[N])
+PT_DEV void block_append(const bool (&e)[N], const uint32_t (&id)[N], uint32_t* const (&c)[N], uint32_t* const (&l)[N], const uint32_t (&top)[N])
 {
+    // top[k] = 0: list k grows upwards from index 0; top[k] = T > 0: it grows DOWNWARDS from index T (the short rays of a kind share
+    // the kind's queue array with its other rays, from the other end)
     constexpr int W = kShadeThreads / 64;
     __shared__ uint32_t s_cnt[N][W];
     __shared__ uint32_t s_base[N];
@@ -104,7 +106,8 @@ PT_DEV void block_append(const bool (&e)[N], const uint32_t (&id)[N], uint32_t* 
     for (int k = 0; k < N; k++) {
         uint32_t pos = s_base[k];
         for (int w = 0; w < wave; w++) pos += s_cnt[k][w];
-        if (e[k]) l[k][pos + (uint32_t)__builtin_popcountll(m[k] & below)] = id[k];
+        pos += (uint32_t)__builtin_popcountll(m[k] & below);
+        if (e[k]) l[k][top[k] ? top[k] - pos : pos] = id[k];
     }
 }
 
@@ -112,10 +115,10 @@ PT_DEV void block_append(const bool (&e)[N], const uint32_t (&id)[N], uint32_t* 
 // wf_init: StartRender prologue for every stream (pathtracer.cu:70-74)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
-void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
+void wf_init(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
 {
     const uint32_t sid = blockIdx.x * 256u + threadIdx.x;
-    bool live = false;
+    bool live = false, camShort = false;
     if (sid < nStreams) {
         const uint32_t unit = (uint32_t)prm.unit_base + (sid >> 6), lane = sid & 63;
         const int pass_rel = (int)(unit / (uint32_t)prm.n_tiles_local);
@@ -127,15 +130,22 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
         live = (tile < prm.n_tiles_total) && (px < cam.W) && (py < cam.H);
         if (live) {
             init_stream(cam, prm, b, sid, px, py, pass);
+            const float4 d0 = b.ray_d[0][sid];
+            camShort = ray_is_short(sc, f3(cam.pos[0], cam.pos[1], cam.pos[2]), f3(d0.x, d0.y, d0.z), 3.0e38f);
         } else {
             b.staging[3 * (size_t)sid + 0] = 0.f; b.staging[3 * (size_t)sid + 1] = 0.f; b.staging[3 * (size_t)sid + 2] = 0.f;
         }
     }
-    const bool e[kLists] = {live, live, false, false};
-    uint32_t* const c[kLists] = {&b.cnt[0].nActive, &b.cnt[0].nRays[0][0], &b.cnt[0].nRays[1][0], &b.cnt[0].nRays[2][0]};
-    uint32_t* const l[kLists] = {b.active[0], b.rq[0], b.rq[1], b.rq[2]};
-    const uint32_t ids[kLists] = {sid, sid, sid, sid};
-    block_append<kLists>(e, ids, c, l);
+    // the camera ray: queued by class like every other ray (a pixel that looks past the mesh has a short ray)
+    const bool shortRay = live && camShort;
+    const uint32_t topIdx = (uint32_t)(b.hit[1] - b.hit[0]) - 1u;      // n16 - 1: the last entry of a queue array
+    const bool e[kLists] = {live, live && !shortRay, false, false, shortRay, false, false};
+    uint32_t* const c[kLists] = {&b.cnt[0].nActive, &b.cnt[0].nRays[0][0], &b.cnt[0].nRays[1][0], &b.cnt[0].nRays[2][0],
+                                 &b.cnt[0].nRays[0][kShortWord], &b.cnt[0].nRays[1][kShortWord], &b.cnt[0].nRays[2][kShortWord]};
+    uint32_t* const l[kLists] = {b.active[0], b.rq[0], b.rq[1], b.rq[2], b.rq[0], b.rq[1], b.rq[2]};
+    const uint32_t ids[kLists] = {sid, sid, sid, sid, sid, sid, sid};
+    const uint32_t top[kLists] = {0u, 0u, 0u, 0u, topIdx, topIdx, topIdx};
+    block_append<kLists>(e, ids, c, l, top);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -151,7 +161,7 @@ void wf_init(DevCamera cam, DevParams prm, WfBuf b, uint32_t nStreams)
 template <int MODE, bool PUBLISH = false>      // PUBLISH: hits are stored device-coherently (wf_shade PHASE 1 reads them while this kernel drains);  MODE: 0 production, 1 trip counters + histograms + timeline (PTAMD_TSTAT=1), 2 timeline only (PTAMD_TSTAT=2), 3 trip counters + section clocks, no per-step atomics (PTAMD_TSTAT=3)
 __global__ __launch_bounds__(256, TRACE_WAVES)
 void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift, int triTrig, int refillMin,
-              int topWant, unsigned long long* stat, int statLaunch)
+              int topWant, unsigned long long* stat, int statLaunch, int helpShards)
 {
     constexpr bool STAT = MODE == 1 || MODE == 3, HIST = MODE == 1, timeline = MODE != 0;
     // PUBLISH launches share the chip with wf_shade's early phase: the traversal is the critical path of the iteration (its last waves
@@ -161,11 +171,17 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
     unsigned long long stTExh = 0;
     unsigned long long stClk[5] = {0, 0, 0, 0, 0}, stMark = 0;      // STAT: shader clocks in refill / vote + budget / node step / triangle step / ray epilogue
     unsigned long long stNodeTrips = 0, stNodeLanes = 0, stTriTrips = 0, stTriLanes = 0, stRefills = 0, stRefillLanes = 0, stNoRayLanes = 0, stRays = 0;
+    unsigned int stTrips = 0, stTripsDry = 0;      // MODE 2: trips of this wave in all, and after it found the queue dry
     __shared__ int lds_stack[4][kWfLdsStack * 64];
-    // one queue index space: [0, nPath) path rays, then the shadow rays of kind 1, then those of kind 2
-    const uint32_t nPath = b.cnt[slot].nRays[0][0];
-    const uint32_t nKind1 = nPath + b.cnt[slot].nRays[1][0];
-    const uint32_t n = nKind1 + b.cnt[slot].nRays[2][0];
+    // one queue index space, six segments: the rays of kind 0 (path), 1 and 2 (shadow) queued from the front of their arrays — rays through
+    // the scene's core box, or of unknown length —, then the SHORT rays of each kind, queued from the back of the same arrays
+    // (pt_stream.h: ray_is_short): what is in flight when the queue runs dry is then short, and so is the launch tail
+    const uint32_t p1 = b.cnt[slot].nRays[0][0];
+    const uint32_t p2 = p1 + b.cnt[slot].nRays[1][0];
+    const uint32_t p3 = p2 + b.cnt[slot].nRays[2][0];
+    const uint32_t p4 = p3 + b.cnt[slot].nRays[0][kShortWord];
+    const uint32_t p5 = p4 + b.cnt[slot].nRays[1][kShortWord];
+    const uint32_t n = p5 + b.cnt[slot].nRays[2][kShortWord];
     if ((uint32_t)blockIdx.x * 256u >= n) return;      // surplus blocks leave before touching the queue (fewer rays per workgroup: no faster, r02_b21.log)
 #if TRACE_TOP_NODES > 0
     __shared__ uint4 lds_top[kTopNodes * kTopStride];
@@ -248,7 +264,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                         chunkPos = start; chunkEnd = (cnt - start > want) ? start + want : cnt; seenLeft = cnt - start; break; }
                     seenLeft = 0xffffffffu;
                     shard = (shard + 1) % kWfShards;
-                    if (++shardsTried >= kWfShards) { exhausted = true; if (timeline) stTExh = __builtin_amdgcn_s_memrealtime(); break; }
+                    if (++shardsTried >= helpShards) { exhausted = true; if (timeline) stTExh = __builtin_amdgcn_s_memrealtime(); break; }
                 }
             }
             if (!exhausted) {
@@ -264,9 +280,13 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
 #else
                         const uint32_t q = ((j / kShardBlock) * kWfShards + (uint32_t)shard) * kShardBlock + (j % kShardBlock);
 #endif
-                        const bool k0 = q < nPath, k1 = q < nKind1;                       // kind 0 / kind 0 or 1
-                        const uint32_t qid = b.rq[0][q + (k0 ? 0u : (k1 ? n16 - nPath : 2u * n16 - nKind1))];
-                        const uint32_t kn = k0 ? 0u : (k1 ? n16 : 2u * n16);              // kind * n16
+                        // segment of q -> kind, position in the kind's queue array (front part upwards, short part downwards from n16 - 1)
+                        const bool shortSeg = q >= p3;
+                        const uint32_t b0 = shortSeg ? p3 : 0u, b1 = shortSeg ? p4 : p1, b2 = shortSeg ? p5 : p2;      // segment starts of kinds 0, 1, 2
+                        const bool k0 = q < b1, k1 = q < b2;                                   // kind 0 / kind 0 or 1
+                        const uint32_t kn = k0 ? 0u : (k1 ? n16 : 2u * n16);                  // kind * n16
+                        const uint32_t local = q - (k0 ? b0 : (k1 ? b1 : b2));
+                        const uint32_t qid = b.rq[0][kn + (shortSeg ? n16 - 1u - local : local)];
                         hs = kn + (qid & ~kResumeBit);
                         const float4 o = ld_s(&b.ray_o[0][hs + kn]), d = ld_s(&b.ray_d[0][hs + kn]);
                         const int kind = k0 ? 0 : 1;      // all that is still asked of it: path ray or not
@@ -297,6 +317,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
         }
         PT_STCLK(0)
         if (__ballot(hasRay) == 0ull) { if (exhausted) break; else continue; }
+        if (MODE == 2) { stTrips++; if (exhausted) stTripsDry++; }
         if (hasRay) {
             // Only one code path runs per trip: a node step or ONE triangle test per lane (the vote is below).
             // (The classic while-while shape made 64 lanes wait for the slowest lane to reach a leaf every
@@ -463,7 +484,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 if (PUBLISH) __hip_atomic_store((unsigned long long*)&b.hit[0][hs], (unsigned long long)__float_as_uint(bestT) | ((unsigned long long)(uint32_t)bestPrim << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else st_s(&b.hit[0][hs], make_float2(bestT, __int_as_float(bestPrim)));
                 hasRay = false;
-                if (STAT) stRays++;
+                if (STAT || MODE == 2) stRays++;
                 if (HIST) atomicAdd(&stat[8 + 3 * 2700 + 32 + 2700 + (steps >= 252 ? 63 : steps >> 2)], 1ull);      // node steps of this ray (this launch), bins of 4
             }
             PT_STCLK(4)
@@ -473,7 +494,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
     if (timeline) {
         // per-lane ray count -> wave total
         unsigned long long r = stRays;
-        if (STAT) for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
+        if (STAT || MODE == 2) for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
         if (lane == 0) {
             if (STAT) { atomicAdd(&stat[0], stNodeTrips); atomicAdd(&stat[1], stNodeLanes); atomicAdd(&stat[2], stTriTrips); atomicAdd(&stat[3], stTriLanes); }
             // launch timeline (100 MHz ticks): earliest wave start, earliest "queue empty", latest wave exit
@@ -485,6 +506,13 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
             const unsigned long long dtk = (tEnd - stT0) / 3200ull;      // 32 us bins (100 MHz ticks)
             atomicAdd(&hist[dtk < 31 ? dtk : 31], 1ull);
             if (blockIdx.x == 0 && threadIdx.x == 0) hist[32 + statLaunch] = n;      // rays of this launch
+            if (MODE == 2) {
+                // per-wave work, all launches pooled: trips per wave (64 bins of 4), trips after the wave found the queue dry (32 bins of 2: in the
+                // slots of MODE 1's per-ray histograms), and rays per wave summed into stat[7] / trips into stat[0] for averages
+                atomicAdd(&stat[8 + 3 * 2700 + 32 + 2700 + (stTrips >= 252 ? 63 : stTrips >> 2)], 1ull);
+                atomicAdd(&stat[8 + 3 * 2700 + 32 + 2700 + 64 + (stTripsDry >= 62 ? 31 : stTripsDry >> 1)], 1ull);
+                atomicAdd(&stat[7], r); atomicAdd(&stat[0], (unsigned long long)stTrips); atomicAdd(&stat[2], (unsigned long long)stTripsDry);
+            }
             if (STAT) { atomicAdd(&stat[4], stRefills); atomicAdd(&stat[5], stRefillLanes); atomicAdd(&stat[6], stNoRayLanes); atomicAdd(&stat[7], r); }
             if (STAT) for (int k = 0; k < 5; k++) atomicAdd(&stat[8 + 3 * 2700 + 32 + 2700 + 64 + 32 + k], stClk[k]);
         }
@@ -506,7 +534,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
 //   PHASE 2 (rest)   runs after both have finished: shades the streams phase 1 skipped and does ALL the appends, in list order — so the
 //                    live list and the ray queues keep stream order exactly as with one launch.
 // A stream goes through the same shade_step either way: result-neutral.
-enum : uint32_t { R_ALIVE = 1, R_EMIT0 = 2, R_EMIT1 = 4, R_EMIT2 = 8, R_DONE = 128 };      // res[]: what phase 1 did with a list position
+enum : uint32_t { R_ALIVE = 1, R_EMIT0 = 2, R_EMIT1 = 4, R_EMIT2 = 8, R_SHORT0 = 16, R_SHORT1 = 32, R_SHORT2 = 64, R_DONE = 128 };      // res[]: what phase 1 did with a list position
 
 PT_DEV float2 load_hit_coherent(const float2* p)
 {
@@ -526,6 +554,7 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
     const bool have = idx < nIn;
     bool alive = false, emit[kRayKinds] = {false, false, false};
     uint32_t sid = 0, resume = 0;      // resume: the queued rays are suspended traversals (wf_trace then reads their records)
+    uint32_t cls = 0;                  // bit k: the ray of kind k this step emitted is short (queued from the back of its queue)
     bool step = have;
     if (have) {
         // While no stream has retired yet (more than half of a render's iterations) every stream is alive, so list position idx can
@@ -537,6 +566,7 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
             if (r & R_DONE) {      // shaded by phase 1: only the appends are left
                 step = false;
                 alive = (r & R_ALIVE) != 0; emit[0] = (r & R_EMIT0) != 0; emit[1] = (r & R_EMIT1) != 0; emit[2] = (r & R_EMIT2) != 0;
+                cls = (r / R_SHORT0) & 7u;
             }
         }
     }
@@ -564,6 +594,7 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
                 store_state(b, sid, st);
                 alive = true;
                 emit[0] = (nf & F_PATH) != 0; emit[1] = (nf & F_SHADOW) != 0; emit[2] = (nf & F_SHADOWA) != 0;
+                cls = st.cls;
             }
         }
     }
@@ -574,14 +605,19 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
         for (int k = 0; k < kRayKinds; k++) if (emit[k]) b.hit[k][sid] = make_float2(0.f, __int_as_float(kNotReady));
     }
     if (PHASE == 1) {
-        if (have) b.res[idx] = (uint8_t)(step ? (R_DONE | (alive ? R_ALIVE : 0u) | (emit[0] ? R_EMIT0 : 0u) | (emit[1] ? R_EMIT1 : 0u) | (emit[2] ? R_EMIT2 : 0u)) : 0u);
+        if (have) b.res[idx] = (uint8_t)(step ? (R_DONE | (alive ? R_ALIVE : 0u) | (emit[0] ? R_EMIT0 : 0u) | (emit[1] ? R_EMIT1 : 0u) | (emit[2] ? R_EMIT2 : 0u) | (cls & 7u) * R_SHORT0) : 0u);
         return;
     }
-    const bool e[kLists] = {alive, emit[0], emit[1], emit[2]};
-    uint32_t* const c[kLists] = {&b.cnt[slotOut].nActive, &b.cnt[slotOut].nRays[0][0], &b.cnt[slotOut].nRays[1][0], &b.cnt[slotOut].nRays[2][0]};
-    uint32_t* const l[kLists] = {b.active[listIn ^ 1], b.rq[0], b.rq[1], b.rq[2]};
-    const uint32_t ids[kLists] = {sid, sid | resume, sid | resume, sid | resume};
-    block_append<kLists>(e, ids, c, l);
+    // a re-queued suspended traversal is long by definition: cls = 0 for it (it never went through the step)
+    const bool s0 = (cls & 1u) != 0, s1 = (cls & 2u) != 0, s2 = (cls & 4u) != 0;
+    const uint32_t topIdx = (uint32_t)(b.hit[1] - b.hit[0]) - 1u;      // n16 - 1
+    const bool e[kLists] = {alive, emit[0] && !s0, emit[1] && !s1, emit[2] && !s2, emit[0] && s0, emit[1] && s1, emit[2] && s2};
+    uint32_t* const c[kLists] = {&b.cnt[slotOut].nActive, &b.cnt[slotOut].nRays[0][0], &b.cnt[slotOut].nRays[1][0], &b.cnt[slotOut].nRays[2][0],
+                                 &b.cnt[slotOut].nRays[0][kShortWord], &b.cnt[slotOut].nRays[1][kShortWord], &b.cnt[slotOut].nRays[2][kShortWord]};
+    uint32_t* const l[kLists] = {b.active[listIn ^ 1], b.rq[0], b.rq[1], b.rq[2], b.rq[0], b.rq[1], b.rq[2]};
+    const uint32_t ids[kLists] = {sid, sid | resume, sid | resume, sid | resume, sid, sid, sid};
+    const uint32_t top[kLists] = {0u, 0u, 0u, 0u, topIdx, topIdx, topIdx};
+    block_append<kLists>(e, ids, c, l, top);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -747,6 +783,9 @@ struct WfTuning {
     int budgetMin;       // PTAMD_BM
     int refillMin;       // PTAMD_RF   idle lanes that trigger a refill
     int triTrig;         // PTAMD_TT   parked leaves that force a triangle trip (64 = only when blocked rays outnumber walking ones)
+    int helpShards;      // PTAMD_HELP shards a wave tries (its own included) before it takes the queue to be dry: 4 (16 = all: every wave then
+                         // spends 16 returning atomics on hot words at the end of every launch; the shards are interleaved and equally long, so
+                         // there is little to help with: 16 -> 4 is +1 % on configs[2], +3 % on configs[1], +4.5 % for an 8-way rank, r03_b20.log)
     int topNodes;        // PTAMD_TOP  quad nodes staged in LDS (TRACE_TOP_NODES builds only)
     // wf_shade: 4 waves/SIMD (126 VGPRs, nothing spilled since the library is built without the SLP vectoriser) in 512-thread workgroups =
     // two per CU; other shapes: 256 threads -4 %, 384 / 768 -13 %, 1024 -8 %, 3 waves/SIMD -9...-13 % (r02_t16_shade_shapes_after_noslp.log)
@@ -770,6 +809,7 @@ static const WfTuning& wf_tuning()
         w.chunkShift = (int)num("PTAMD_CS", 12); w.guideShift = (int)num("PTAMD_GS", 9);
         w.budgetShift = (int)num("PTAMD_BS", 14); w.budgetMin = (int)num("PTAMD_BM", ptd::kWfBudget);
         w.refillMin = (int)num("PTAMD_RF", ptd::kWfRefill); w.triTrig = (int)num("PTAMD_TT", 64); w.topNodes = (int)num("PTAMD_TOP", ptd::kTopNodes);
+        w.helpShards = (int)num("PTAMD_HELP", 4); if (w.helpShards < 1) w.helpShards = 1; if (w.helpShards > ptd::kWfShards) w.helpShards = ptd::kWfShards;
         w.shadeWaves = (int)num("PTAMD_SW", 4); w.shadeThreads = threads("PTAMD_ST", 512);
         w.trStreams = (uint32_t)num("PTAMD_TRS", 4000000);
         w.earlyThreads = threads("PTAMD_EST", 64); w.earlyPrio = (int)num("PTAMD_EPRIO", 0); w.pubOnly = num("PTAMD_EPUB", 0) != 0;
@@ -792,7 +832,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     const size_t nStreams = (size_t)prm.n_units * 64;
     if ((e = hipMemsetAsync(b.cnt, 0, 3 * kWfSlotBytes, stream)) != hipSuccess) return e;
     const int nb = (int)((nStreams + 255) / 256);
-    hipLaunchKernelGGL(wf_init, dim3(nb), dim3(256), 0, stream, *cam, prm, b, (uint32_t)nStreams);
+    hipLaunchKernelGGL(wf_init, dim3(nb), dim3(256), 0, stream, *sc, *cam, prm, b, (uint32_t)nStreams);
     const int ovfStride = traceBlocks * 256;
     const int tb = traceBlocks < nb ? traceBlocks : nb;
     // every sample needs at most max_bounce + (max_refract + 2) bounces, +1 iteration to retire
@@ -824,11 +864,11 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
                 if ((e = hipEventRecord(evOvl[it & 1], stream)) != hipSuccess) return e;
                 if ((e = hipStreamWaitEvent(aux, evOvl[it & 1], 0)) != hipSuccess) return e;
             }
-            if (traceStat && traceStatClk) hipLaunchKernelGGL(wf_trace<3>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
-            else if (traceStat && traceStatFull) hipLaunchKernelGGL(wf_trace<1>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
-            else if (traceStat) hipLaunchKernelGGL(wf_trace<2>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699);
-            else if (early || pubOnly) hipLaunchKernelGGL((wf_trace<0, true>), dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, earlyPrio);
-            else hipLaunchKernelGGL(wf_trace<0>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, 0);
+            if (traceStat && traceStatClk) hipLaunchKernelGGL(wf_trace<3>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699, tn.helpShards);
+            else if (traceStat && traceStatFull) hipLaunchKernelGGL(wf_trace<1>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699, tn.helpShards);
+            else if (traceStat) hipLaunchKernelGGL(wf_trace<2>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699, tn.helpShards);
+            else if (early || pubOnly) hipLaunchKernelGGL((wf_trace<0, true>), dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, earlyPrio, tn.helpShards);
+            else hipLaunchKernelGGL(wf_trace<0>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, 0, tn.helpShards);
             if (timed) (void)hipEventRecord(trace_ev[3 * it + 1], stream);
             const dim3 sg((liveBound + shadeThreads - 1) / shadeThreads), sb(shadeThreads);
             const bool twoRounds = shadeRounds >= 0 ? (shadeRounds != 0) : (liveBound < trStreams);

@@ -192,6 +192,35 @@ int main(int argc, char** argv)
         gen.swap(next);
     }
     printf("%zu rays (camera, 2 bounce generations, shadow)\n", rays.size());
+    // ---- ray classes by the "core box" (round 3, queue ordering): the AABB of the small triangles; a ray whose segment misses it can only
+    // meet the few big triangles: is it really short, and how many rays are there?
+    {
+        const PtTriangle* T = pt_bvh_tris(bvh);
+        const int nT = pt_bvh_num_tris(bvh);
+        float smn[3] = {1e30f, 1e30f, 1e30f}, smx[3] = {-1e30f, -1e30f, -1e30f};
+        for (int i = 0; i < nT; i++) for (int a = 0; a < 3; a++) { const float v[3] = {T[i].V0[a], T[i].V1[a], T[i].V2[a]}; for (float x : v) { smn[a] = std::min(smn[a], x); smx[a] = std::max(smx[a], x); } }
+        const float sdiag = std::sqrt((smx[0]-smn[0])*(smx[0]-smn[0]) + (smx[1]-smn[1])*(smx[1]-smn[1]) + (smx[2]-smn[2])*(smx[2]-smn[2]));
+        float cmn[3] = {1e30f, 1e30f, 1e30f}, cmx[3] = {-1e30f, -1e30f, -1e30f}; int nSmall = 0;
+        for (int i = 0; i < nT; i++) {
+            float mn[3], mx[3]; float d2 = 0.f;
+            for (int a = 0; a < 3; a++) { mn[a] = std::min(T[i].V0[a], std::min(T[i].V1[a], T[i].V2[a])); mx[a] = std::max(T[i].V0[a], std::max(T[i].V1[a], T[i].V2[a])); d2 += (mx[a]-mn[a])*(mx[a]-mn[a]); }
+            if (std::sqrt(d2) * 8.f < sdiag) { nSmall++; for (int a = 0; a < 3; a++) { cmn[a] = std::min(cmn[a], mn[a]); cmx[a] = std::max(cmx[a], mx[a]); } }
+        }
+        printf("core box: %d of %d triangles are small; [%.1f %.1f %.1f] - [%.1f %.1f %.1f] in scene [%.1f %.1f %.1f] - [%.1f %.1f %.1f]\n", nSmall, nT, cmn[0], cmn[1], cmn[2], cmx[0], cmx[1], cmx[2], smn[0], smn[1], smn[2], smx[0], smx[1], smx[2]);
+        double cnt[2][2] = {{0,0},{0,0}}, sum[2][2] = {{0,0},{0,0}}, mxs[2][2] = {{0,0},{0,0}}, ge24[2][2] = {{0,0},{0,0}};
+        for (const Ray& r : rays) {
+            float t0 = 0.f, t1 = r.tmax;
+            const float o[3] = {r.o.x, r.o.y, r.o.z}, d[3] = {r.d.x, r.d.y, r.d.z};
+            for (int a = 0; a < 3; a++) { const float iv = 1.f / d[a]; float a0 = (cmn[a] - o[a]) * iv, a1 = (cmx[a] - o[a]) * iv; if (a0 > a1) std::swap(a0, a1); t0 = std::fmax(t0, a0); t1 = std::fmin(t1, a1); }
+            const int miss = !(t0 <= t1);
+            Cnt c; float t; trace(r, 0, c, t, nullptr);
+            const int k = r.any ? 1 : 0;
+            const double st = c.nodes + c.leaves;
+            cnt[k][miss]++; sum[k][miss] += st; mxs[k][miss] = std::max(mxs[k][miss], st); ge24[k][miss] += st >= 24;
+        }
+        for (int k = 0; k < 2; k++) for (int m = 0; m < 2; m++)
+            printf("  %-7s rays %-22s: %8.0f (%.1f %%)  trips/ray mean %5.2f  max %3.0f  share with >= 24 trips %.4f\n", k ? "shadow" : "path", m ? "missing the core box" : "through the core box", cnt[k][m], 100.0 * cnt[k][m] / rays.size(), sum[k][m] / std::max(1.0, cnt[k][m]), mxs[k][m], ge24[k][m] / std::max(1.0, cnt[k][m]));
+    }
     static const char* name[4] = {"exact sort", "axis order", "nearest + slot order", "slot order"};
     Cnt base;
     for (int pol = 0; pol < 4; pol++) {
