@@ -299,8 +299,9 @@ PT_API int  pt_trace_timing(PtScene* s, double* sum_ms, int32_t* launches, doubl
 PT_API int  pt_shade_timing(PtScene* s, double* sum_ms, int32_t* launches, double* max_ms);
 PT_API int  pt_last_iterations(PtScene* s);
 /* Mode 1 hands the last streams of a render to one run-to-completion launch (wf_drain) once at
- * most `live_streams` are still alive (0 = never, the default: on MI355X the drain launch measured
- * slower than the latency-bound iterations it replaces).  Result-neutral. */
+ * most `live_streams` are still alive (0 = never; default 48,000: the launch, its streams spread over every SIMD,
+ * replaces the last ~200 latency-bound iterations of a render — +5 % for one rank of an 8-way split, +1 % on one GPU).
+ * Result-neutral. */
 PT_API int  pt_set_drain_threshold(PtScene* s, int32_t live_streams);
 /* Mode 1, early shade: in a render call of at most `max_streams` streams (pixels of this rank x passes of the call) the shade step of
  * every iteration starts on a second HIP stream beside the draining traversal kernel (streams whose rays are all back are shaded at

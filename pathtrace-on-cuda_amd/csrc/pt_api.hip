@@ -49,7 +49,7 @@ void pt_set_error(const char* fmt, ...);   // pt_host.cpp
         }                                                                                   \
     } while (0)
 
-static const size_t kCounterBytes = 64 + 2700 * 3 * 8 + 32 * 8 + 2700 * 8 + 64 * 8 + 32 * 8 + 8 * 8;   // 8 work counters + diagnostic launch timeline (3 x u64 per wf_trace launch) + wave-lifetime histogram + rays per launch
+static const size_t kCounterBytes = ptd::kStatBytes;   // 8 work counters + diagnostic launch timeline (3 x u64 per wf_trace launch) + wave-lifetime histogram + rays per launch
 
 struct PtScene {
     int device = 0;
@@ -69,7 +69,10 @@ struct PtScene {
     int last_iters = 0;
     int shade_rounds = 1;        // wf_shade: 1 = a stream may start its next sample in the step its path ends, 0 = one bounce per step, -1 = by live-stream count (PTAMD_TRS)
     int early_below = 2500000;   // renders of at most this many streams (pixels x passes of one call) run wf_shade's early phase beside the draining wf_trace (0 = never; pt_set_early_shade)
-    int drain_below = 0;         // hand the last streams to wf_drain once this few are live (0 = never; measured slower than the tail it replaces)
+    int drain_below = 48000;     // hand the last streams of a render to wf_drain once this few are live (0 = never; PTAMD_DRAIN, pt_set_drain_threshold):
+                                 // the last ~200 of ~1,100 bounce iterations serve < 5 % of the streams at the latency of the longest ray each
+                                 // (~200 us); wf_drain runs those streams to their end in one launch, spread over every SIMD.  40,000-80,000 is flat:
+                                 // +5 % for an 8-way rank, +3 % 4-way, +1 % on one GPU (r03_b31.log, r03_b32.log)
     // optional per-launch timing of the traversal kernel (pt_enable_trace_timing)
     std::vector<hipEvent_t> trace_ev;
     int trace_ev_used[4] = {0, 0, 0, 0};     // per cohort
@@ -549,7 +552,15 @@ PT_API int pt_set_shade_rounds(PtScene* s, int32_t mode)
 // Ask the next pt_render_tiles on this scene to run the counting build of the kernel.
 int pt_dbg_trace_timeline(PtScene* s, int64_t* out3n, int32_t n_launches)
 {
-    if (!s || !out3n || (n_launches < -2700 && n_launches != -3000 && n_launches != -3001 && n_launches != -3002) || n_launches > 2700) { pt_set_error("pt_dbg_trace_timeline: bad arguments"); return PT_ERR_INVALID; }
+    if (!s || !out3n || (n_launches < -2700 && (n_launches > -3000 || n_launches < -3004)) || n_launches > 2700) { pt_set_error("pt_dbg_trace_timeline: bad arguments"); return PT_ERR_INVALID; }
+    if (n_launches == -3003 || n_launches == -3004) {      // PTAMD_TSTAT=2 + PTAMD_TDUMP=launch: 8 x int64 per wave (kStatWaves) / the per-trip log (kStatLogWaves x kStatLogTrips uint32)
+        HIPCHK(hipSetDevice(s->device));
+        HIPCHK(hipDeviceSynchronize());
+        const size_t off = (size_t)ptd::kStatWords * 8, wb = (size_t)ptd::kStatWaves * 64;
+        if (n_launches == -3003) HIPCHK(hipMemcpy(out3n, (const char*)s->d_counters + off, wb, hipMemcpyDeviceToHost));
+        else HIPCHK(hipMemcpy(out3n, (const char*)s->d_counters + off + wb, (size_t)ptd::kStatLogWaves * ptd::kStatLogTrips * 4, hipMemcpyDeviceToHost));
+        return PT_OK;
+    }
     if (n_launches == -3002) {      // shader clocks per section of wf_trace's loop, summed over waves (5 x int64: refill, vote, node step, triangle step, epilogue), PTAMD_TSTAT=1
         HIPCHK(hipSetDevice(s->device));
         HIPCHK(hipDeviceSynchronize());
@@ -576,6 +587,18 @@ int pt_dbg_trace_timeline(PtScene* s, int64_t* out3n, int32_t n_launches)
     }
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipDeviceSynchronize());
+    static const bool kStriped = getenv("PTAMD_TSTAT") && atoi(getenv("PTAMD_TSTAT")) == 2;
+    if (kStriped && n_launches > 0) {
+        // the timestamp-only build keeps kStatStripes copies of every launch's three words (maxima of ~start, ~dry, end)
+        std::vector<unsigned long long> raw((size_t)n_launches * ptd::kStatStripes * 3);
+        HIPCHK(hipMemcpy(raw.data(), (const char*)s->d_counters + ptd::kStatStripeOff, raw.size() * 8, hipMemcpyDeviceToHost));
+        for (int l = 0; l < n_launches; l++)
+            for (int k = 0; k < 3; k++) {
+                unsigned long long m = 0;
+                for (int st = 0; st < ptd::kStatStripes; st++) { const unsigned long long v = raw[((size_t)l * ptd::kStatStripes + st) * 3 + k]; if (v > m) m = v; }
+                out3n[(size_t)l * 3 + k] = (int64_t)m;
+            }
+    } else
     HIPCHK(hipMemcpy(out3n, (const char*)s->d_counters + 64, (size_t)n_launches * 24, hipMemcpyDeviceToHost));
     if (n_launches == 0 && out3n) HIPCHK(hipMemcpy(out3n, (const char*)s->d_counters + 64 + 2700 * 24, 32 * 8, hipMemcpyDeviceToHost));   // n = 0: the 32-bin histogram of wave lifetimes (32 us bins)
     return PT_OK;

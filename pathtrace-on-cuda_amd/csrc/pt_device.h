@@ -48,6 +48,14 @@ constexpr int kStackDepth = 32;          // per-lane traversal stack entries (LD
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlockThreads = 64 * kWavesPerBlock;
 
+// Diagnostic counter buffer (PtScene::d_counters, PTAMD_TSTAT): kStatWords 64-bit words of counters, launch timeline and histograms,
+// then — for one chosen launch of wf_trace (PTAMD_TDUMP) — 8 words per wave (kStatWaves) and a per-trip log of every kStatLogEvery-th wave
+constexpr int kStatWords = 8 + 2700 * 3 + 32 + 2700 + 64 + 32 + 8;
+constexpr int kStatWaves = 8192, kStatLogEvery = 112, kStatLogWaves = 64, kStatLogTrips = 1024;
+constexpr int kStatStripes = 64;      // MODE 2: the launch timeline is kept in 64 copies (workgroup % 64), reduced on the host — one word per launch was 7,168 atomics on one address
+constexpr size_t kStatStripeOff = (size_t)kStatWords * 8 + (size_t)kStatWaves * 64 + (size_t)kStatLogWaves * kStatLogTrips * 4;      // bytes
+constexpr size_t kStatBytes = kStatStripeOff + (size_t)2700 * kStatStripes * 3 * 8;
+
 struct DevScene {
     const float4* nodes;      // traversal tree (SAH over triangles), 4 x float4 per record
     const uint4* quad;        // its 4-wide quantised collapse, 4 x uint4 per record (wf_trace)

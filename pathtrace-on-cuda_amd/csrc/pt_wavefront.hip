@@ -88,7 +88,6 @@ PT_DEV void block_append(const bool (&e)[N], const uint32_t (&id)[N], uint32_t* 
     // the kind's queue array with its other rays, from the other end)
     constexpr int W = kShadeThreads / 64;
     __shared__ uint32_t s_cnt[N][W];
-    __shared__ uint32_t s_base[N];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = (int)(blockDim.x >> 6);
     unsigned long long m[N];
@@ -96,17 +95,18 @@ PT_DEV void block_append(const bool (&e)[N], const uint32_t (&id)[N], uint32_t* 
     for (int k = 0; k < N; k++) { m[k] = __ballot(e[k]); if (lane == 0) s_cnt[k][wave] = __builtin_popcountll(m[k]); }
     __syncthreads();
     if (threadIdx.x < N) {
+        // one thread per list: the block's total -> one atomic, and every wave's count turned into its start position in place
+        // (every thread summing the counts of the waves below its own: 7 lists x up to 7 LDS reads per thread, -1.3 % overall, r03_b26.log)
         uint32_t tot = 0;
         for (int w = 0; w < nw; w++) tot += s_cnt[threadIdx.x][w];
-        s_base[threadIdx.x] = tot ? atomicAdd(c[threadIdx.x], tot) : 0u;
+        uint32_t run = tot ? atomicAdd(c[threadIdx.x], tot) : 0u;
+        for (int w = 0; w < nw; w++) { const uint32_t v = s_cnt[threadIdx.x][w]; s_cnt[threadIdx.x][w] = run; run += v; }
     }
     __syncthreads();
     const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        uint32_t pos = s_base[k];
-        for (int w = 0; w < wave; w++) pos += s_cnt[k][w];
-        pos += (uint32_t)__builtin_popcountll(m[k] & below);
+        const uint32_t pos = s_cnt[k][wave] + (uint32_t)__builtin_popcountll(m[k] & below);
         if (e[k]) l[k][top[k] ? top[k] - pos : pos] = id[k];
     }
 }
@@ -172,6 +172,10 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
     unsigned long long stClk[5] = {0, 0, 0, 0, 0}, stMark = 0;      // STAT: shader clocks in refill / vote + budget / node step / triangle step / ray epilogue
     unsigned long long stNodeTrips = 0, stNodeLanes = 0, stTriTrips = 0, stTriLanes = 0, stRefills = 0, stRefillLanes = 0, stNoRayLanes = 0, stRays = 0;
     unsigned int stTrips = 0, stTripsDry = 0;      // MODE 2: trips of this wave in all, and after it found the queue dry
+    // MODE 2, one chosen launch (PTAMD_TDUMP; stat[6] = launch + 1): a record per wave (kStatWaveRec) and a per-trip log of every 112th wave
+    const bool stDump = MODE == 2 && stat[6] == (unsigned long long)statLaunch + 1ull;
+    const uint32_t stWave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const bool stLog = stDump && stWave % kStatLogEvery == 0 && stWave / kStatLogEvery < (uint32_t)kStatLogWaves;
     __shared__ int lds_stack[4][kWfLdsStack * 64];
     // one queue index space, six segments: the rays of kind 0 (path), 1 and 2 (shadow) queued from the front of their arrays — rays through
     // the scene's core box, or of unknown length —, then the SHORT rays of each kind, queued from the back of the same arrays
@@ -234,6 +238,13 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
         // ---- hand new rays to idle lanes (ballot + mbcnt compaction) ----
         if (STAT) stMark = __builtin_amdgcn_s_memtime();
 #define PT_STCLK(k) if (STAT) { const unsigned long long now = __builtin_amdgcn_s_memtime(); stClk[k] += now - stMark; stMark = now; }
+        uint32_t stW0 = 0, stAtomics = 0, stTook = 0;      // MODE 2 trip log: time at the top of the loop, queue atomics and rays taken in this iteration
+        uint32_t stW1 = 0, stW3 = 0;
+        if (MODE == 2 && stLog) {
+            // A = top of the loop, on the constant 100 MHz clock, and the shader clock counter at the same moment (their ratio is the clock the SIMD runs at)
+            stW0 = (uint32_t)((__builtin_amdgcn_s_memrealtime() - stT0) & 0xfffffull);
+            stW1 = (uint32_t)__builtin_amdgcn_s_memtime();
+        }
         const unsigned long long idle = __ballot(!hasRay);
         const int nIdle = __builtin_popcountll(idle);
         if (!exhausted && (nIdle >= refillMin)) {
@@ -259,6 +270,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                     want = want < 16u ? 16u : (want > kChunk ? kChunk : want);
                     uint32_t start = 0;
                     if (lane == 0) start = atomicAdd(&b.cnt[slot].head[shard].v, want);
+                    if (MODE == 2) stAtomics++;
                     start = __builtin_amdgcn_readfirstlane(start);
                     if (start < cnt) {
                         chunkPos = start; chunkEnd = (cnt - start > want) ? start + want : cnt; seenLeft = cnt - start; break; }
@@ -271,6 +283,7 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 const uint32_t avail = chunkEnd - chunkPos;
                 const uint32_t take = ((uint32_t)nIdle < avail) ? (uint32_t)nIdle : avail;
                 if (STAT && take) { stRefills++; stRefillLanes += take; }
+                if (MODE == 2) stTook = take;
                 if (!hasRay) {
                     const uint32_t r = (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
                     if (r < take) {
@@ -318,6 +331,20 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
         PT_STCLK(0)
         if (__ballot(hasRay) == 0ull) { if (exhausted) break; else continue; }
         if (MODE == 2) { stTrips++; if (exhausted) stTripsDry++; }
+        uint32_t* stLogAt = nullptr;
+        if (MODE == 2 && stLog && 4 * stTrips <= (unsigned)kStatLogTrips) {
+            // four words per trip (10-ns ticks since the wave started in the low 20 bits).  w0: A, top of the loop | lanes with a ray (7 bits) | queue
+            // already dry | queue atomics of the refill (2 bits, saturating); w1: the shader clock counter at A (low 32 bits);
+            // w2: C, after the refill | rays taken (7) | some lane holds a leaf; w3: D, node data of a node trip arrived (0 for a triangle trip)
+            const uint32_t lanesNow = (uint32_t)__builtin_popcountll(__ballot(hasRay)), pendNow = (uint32_t)__builtin_popcountll(__ballot(hasRay && pend != 0));
+            stLogAt = (uint32_t*)(stat + kStatWords + (size_t)kStatWaves * 8) + (size_t)(stWave / kStatLogEvery) * kStatLogTrips + 4 * (stTrips - 1);
+            if (lane == 0) {
+                stLogAt[0] = stW0 | (lanesNow << 20) | (exhausted ? 1u << 27 : 0u) | ((stAtomics > 3u ? 3u : stAtomics) << 28);
+                stLogAt[1] = stW1;
+                stLogAt[2] = (uint32_t)((__builtin_amdgcn_s_memrealtime() - stT0) & 0xfffffull) | ((stTook > 127u ? 127u : stTook) << 20) | (pendNow ? 1u << 27 : 0u);
+                stLogAt[3] = 0u;
+            }
+        }
         if (hasRay) {
             // Only one code path runs per trip: a node step or ONE triangle test per lane (the vote is below).
             // (The classic while-while shape made 64 lanes wait for the slowest lane to reach a leaf every
@@ -379,6 +406,11 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
                 {
                     const uint4* np = sc.quad + 4 * (size_t)cur;
                     n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3];
+                }
+                if (MODE == 2 && stLogAt) {
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(n0.x), "+v"(n1.x), "+v"(n2.x), "+v"(n3.x) :: "memory");
+                    stW3 = (uint32_t)((__builtin_amdgcn_s_memrealtime() - stT0) & 0xfffffull);
+                    stLogAt[3] = stW3;      // every lane of the node trip writes the same word
                 }
                 const float Ax = inv.x * __uint_as_float(n0.w), Ay = inv.y * __uint_as_float(n3.z), Az = inv.z * __uint_as_float(n3.w);      // scales are powers of two
                 const float Bx = (__uint_as_float(n0.x) - org.x) * inv.x;
@@ -495,17 +527,30 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
         // per-lane ray count -> wave total
         unsigned long long r = stRays;
         if (STAT || MODE == 2) for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
-        if (lane == 0) {
+        if (lane == 0 && stDump) {
+            // the dumped launch: one record per wave and none of the pooled statistics below (their atomics on a few hot words come from
+            // every wave as it leaves, i.e. all through the launch tail that is being looked at)
+            if (stWave < (uint32_t)kStatWaves) {
+                unsigned long long* w = stat + kStatWords + (size_t)stWave * 8;
+                w[0] = stT0; w[1] = stTExh; w[2] = __builtin_amdgcn_s_memrealtime(); w[3] = stTrips; w[4] = stTripsDry; w[5] = r;
+                w[6] = __builtin_amdgcn_s_getreg(4 | (31 << 11));       // HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]
+                w[7] = __builtin_amdgcn_s_getreg(20 | (31 << 11));      // XCC_ID
+            }
+        } else if (lane == 0) {
             if (STAT) { atomicAdd(&stat[0], stNodeTrips); atomicAdd(&stat[1], stNodeLanes); atomicAdd(&stat[2], stTriTrips); atomicAdd(&stat[3], stTriLanes); }
             // launch timeline (100 MHz ticks): earliest wave start, earliest "queue empty", latest wave exit
-            unsigned long long* tl = stat + 8 + 3 * (size_t)statLaunch;
+            // MODE 2 keeps it in kStatStripes copies and nothing else unless stat[5] asks for the pooled histograms (PTAMD_TPOOL=1): atomics from
+            // every leaving wave on a handful of words stretched the very tail they were meant to measure (r03_b27.log: a launch of 100 us
+            // became one of 287 us)
+            unsigned long long* tl = MODE == 2 ? stat + kStatStripeOff / 8 + 3 * ((size_t)statLaunch * kStatStripes + (blockIdx.x % kStatStripes)) : stat + 8 + 3 * (size_t)statLaunch;
             const unsigned long long tEnd = __builtin_amdgcn_s_memrealtime();
             atomicMax(&tl[0], ~stT0); if (stTExh) atomicMax(&tl[1], ~stTExh); atomicMax(&tl[2], tEnd);
+            if (blockIdx.x == 0 && threadIdx.x == 0) stat[8 + 3 * 2700 + 32 + statLaunch] = n;      // rays of this launch
+            if (MODE == 2 && stat[5] == 0ull) return;
             // distribution of wave exit times over the launch, all launches pooled (absolute: 32 us bins)
             unsigned long long* hist = stat + 8 + 3 * 2700;
             const unsigned long long dtk = (tEnd - stT0) / 3200ull;      // 32 us bins (100 MHz ticks)
             atomicAdd(&hist[dtk < 31 ? dtk : 31], 1ull);
-            if (blockIdx.x == 0 && threadIdx.x == 0) hist[32 + statLaunch] = n;      // rays of this launch
             if (MODE == 2) {
                 // per-wave work, all launches pooled: trips per wave (64 bins of 4), trips after the wave found the queue dry (32 bins of 2: in the
                 // slots of MODE 1's per-ray histograms), and rays per wave summed into stat[7] / trips into stat[0] for averages
@@ -630,11 +675,15 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
 // shade_step.  Pending time-sliced traversals are simply redone (they are deterministic).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlockThreads)
-void wf_drain(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, int listIn)
+void wf_drain(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, int listIn, int spreadShift)
 {
     __shared__ int lds_stack[kWavesPerBlock][kStackDepth * 64];
     const uint32_t nIn = b.cnt[slotIn].nActive;
-    const uint32_t idx = blockIdx.x * (uint32_t)kBlockThreads + threadIdx.x;
+    // spreadShift: only every 2^s-th lane carries a stream.  The kernel is bound by latency (a wave steps at the pace of its slowest
+    // lane, every bounce), and the chip is far from full at this point: thinner waves wait for the maximum of fewer paths
+    const uint32_t t = blockIdx.x * (uint32_t)kBlockThreads + threadIdx.x;
+    if (t & ((1u << spreadShift) - 1u)) return;
+    const uint32_t idx = t >> spreadShift;
     if (idx >= nIn) return;
     int* stack = &lds_stack[threadIdx.x >> 6][threadIdx.x & 63];
     const uint32_t sid = b.active[listIn][idx];
@@ -798,6 +847,9 @@ struct WfTuning {
     int earlyThreads;    // PTAMD_EST  threads per workgroup of wf_shade's early phase (64: one free wave slot is enough; 512 / 256 / 128 / 64 -> 0.488 / 0.481 / 0.473 / 0.472 s for an 8-way rank)
     int earlyPrio;       // PTAMD_EPRIO issue priority of the traversal waves while the early phase runs beside them (no effect measured)
     bool pubOnly;        // PTAMD_EPUB  A/B: device-scope hit stores and marks, but no early phase
+    int drainSpread;     // PTAMD_DSPREAD  wf_drain: at most every 2^this-th lane carries a stream (3)
+    bool tracePool;      // PTAMD_TPOOL with PTAMD_TSTAT=2: also the pooled per-wave histograms (tools/wave_exit_hist.py) — their atomics lengthen the launch tail
+    int traceDump;       // PTAMD_TDUMP with PTAMD_TSTAT=2: the wf_trace launch (iteration) whose waves are dumped one by one (pt_dbg_trace_timeline -3003 / -3004)
     int traceStat;       // PTAMD_TSTAT 1 trip counters + histograms (slower build), 2 timeline only (production code path), 3 trip counters + section clocks
 };
 static const WfTuning& wf_tuning()
@@ -814,6 +866,9 @@ static const WfTuning& wf_tuning()
         w.trStreams = (uint32_t)num("PTAMD_TRS", 4000000);
         w.earlyThreads = threads("PTAMD_EST", 64); w.earlyPrio = (int)num("PTAMD_EPRIO", 0); w.pubOnly = num("PTAMD_EPUB", 0) != 0;
         w.traceStat = (int)num("PTAMD_TSTAT", 0);
+        w.traceDump = (int)num("PTAMD_TDUMP", -1);
+        w.tracePool = num("PTAMD_TPOOL", 0) != 0;
+        w.drainSpread = (int)num("PTAMD_DSPREAD", 3); if (w.drainSpread < 0) w.drainSpread = 0; if (w.drainSpread > 5) w.drainSpread = 5;
         return w;
     }();
     return t;
@@ -843,6 +898,15 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
     const int earlyPrio = tn.earlyPrio, earlyThreads = tn.earlyThreads, refillMin = tn.refillMin, triTrig = tn.triTrig, chunkShift = tn.chunkShift, topNodes = tn.topNodes;
     const bool pubOnly = tn.pubOnly, traceStatClk = tn.traceStat == 3, traceStatFull = tn.traceStat == 1;
     const uint32_t trStreams = tn.trStreams;
+    if (traceStat && tn.traceStat == 2 && tn.tracePool) {
+        static const unsigned long long one = 1ull;
+        if ((e = hipMemcpyAsync(traceStat + 5, &one, 8, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    }
+    if (traceStat && tn.traceStat == 2 && tn.traceDump >= 0) {
+        // diagnostic: wf_trace dumps a record per wave for this one launch (the word was cleared with the rest of the buffer by the caller)
+        static unsigned long long dumpWord; dumpWord = (unsigned long long)tn.traceDump + 1ull;
+        if ((e = hipMemcpyAsync(traceStat + 6, &dumpWord, 8, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    }
     int it = 0;
     int poll = 16;
     // streams only ever retire, so the live count of the last poll bounds every later one: the shade grid
@@ -895,14 +959,18 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
         liveBound = h_cnt[0];
         if (h_cnt[0] <= (uint32_t)drainBelow) {
             // few streams left: finish them in one launch instead of hundreds of latency-bound iterations
-            const int db = (int)((h_cnt[0] + kBlockThreads - 1) / kBlockThreads);
-            hipLaunchKernelGGL(wf_drain, dim3(db), dim3(kBlockThreads), 0, stream, *sc, *cam, prm, b, it % 3, it & 1);
+            // 3 waves per SIMD of wf_drain fit (165 VGPRs): spread the streams over at most that many lanes
+            int spread = 0;
+            while (spread < tn.drainSpread && ((size_t)h_cnt[0] << (spread + 1)) <= (size_t)3 * 4 * 256 * 64) spread++;
+            const int db = (int)((((size_t)h_cnt[0] << spread) + kBlockThreads - 1) / kBlockThreads);
+            hipLaunchKernelGGL(wf_drain, dim3(db), dim3(kBlockThreads), 0, stream, *sc, *cam, prm, b, it % 3, it & 1, spread);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
             break;
         }
         if (it > hardCap) return hipErrorLaunchFailure;      // cannot happen for a well-formed scene; never spin forever
         if (poll < 64) poll *= 2;
+        if (drainBelow > 0 && h_cnt[0] <= (uint32_t)drainBelow * 8u) poll = 16;      // near the hand-over: look again soon
     }
     if (iters_out) *iters_out = it;
     if (trace_ev_used) *trace_ev_used = trace_ev ? (it < trace_ev_pairs ? it : trace_ev_pairs) : 0;

@@ -3,6 +3,7 @@
 timestamps, PTAMD_TSTAT=2) next to the launch timeline.  usage: wave_exit_hist.py [kind W H passes spp [world rank]]"""
 import ctypes as C, os, sys
 os.environ["PTAMD_TSTAT"] = "2"
+os.environ["PTAMD_TPOOL"] = "1"      # the pooled histograms: their atomics lengthen the tail (see r03_b27.log) — shapes only
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pathtrace-on-cuda_amd"))
 import numpy as np, torch, ptamd
