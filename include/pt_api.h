@@ -299,7 +299,7 @@ PT_API int  pt_trace_timing(PtScene* s, double* sum_ms, int32_t* launches, doubl
 PT_API int  pt_shade_timing(PtScene* s, double* sum_ms, int32_t* launches, double* max_ms);
 PT_API int  pt_last_iterations(PtScene* s);
 /* Mode 1 hands the last streams of a render to one run-to-completion launch (wf_drain) once at
- * most `live_streams` are still alive (0 = never; default 48,000: the launch, its streams spread over every SIMD,
+ * most `live_streams` are still alive (0 = never; default 80,000: the launch, its streams spread over every SIMD,
  * replaces the last ~200 latency-bound iterations of a render — +5 % for one rank of an 8-way split, +1 % on one GPU).
  * Result-neutral. */
 PT_API int  pt_set_drain_threshold(PtScene* s, int32_t live_streams);

@@ -69,10 +69,10 @@ struct PtScene {
     int last_iters = 0;
     int shade_rounds = 1;        // wf_shade: 1 = a stream may start its next sample in the step its path ends, 0 = one bounce per step, -1 = by live-stream count (PTAMD_TRS)
     int early_below = 2500000;   // renders of at most this many streams (pixels x passes of one call) run wf_shade's early phase beside the draining wf_trace (0 = never; pt_set_early_shade)
-    int drain_below = 48000;     // hand the last streams of a render to wf_drain once this few are live (0 = never; PTAMD_DRAIN, pt_set_drain_threshold):
+    int drain_below = 80000;     // hand the last streams of a render to wf_drain once this few are live (0 = never; PTAMD_DRAIN, pt_set_drain_threshold):
                                  // the last ~200 of ~1,100 bounce iterations serve < 5 % of the streams at the latency of the longest ray each
-                                 // (~200 us); wf_drain runs those streams to their end in one launch, spread over every SIMD.  40,000-80,000 is flat:
-                                 // +5 % for an 8-way rank, +3 % 4-way, +1 % on one GPU (r03_b31.log, r03_b32.log)
+                                 // (~200 us); wf_drain runs those streams to their end in one launch, spread over every SIMD.  40,000-120,000 is flat:
+                                 // +5...7 % for an 8-way rank, +3 % 4-way, +1 % on one GPU (r03_b31.log, r03_b32.log, r03_b33.log)
     // optional per-launch timing of the traversal kernel (pt_enable_trace_timing)
     std::vector<hipEvent_t> trace_ev;
     int trace_ev_used[4] = {0, 0, 0, 0};     // per cohort
@@ -296,7 +296,7 @@ int pt_scene_create(const PtBVHNode* nodes, int32_t n_nodes, const PtTriangle* t
     sc->dev.tripair = (const float4*)sc->d_tripair;
     sc->dev.leafbox = (const float4*)sc->d_leafbox; sc->dev.surf = (const float4*)sc->d_surf;
     sc->dev.lights = (const float4*)sc->d_lights; sc->dev.spheres = (const float4*)sc->d_spheres;
-    sc->dev.n_quad = accel.n_quad;
+    sc->dev.n_quad = accel.n_quad; sc->dev.quad_depth = accel.quad_depth;
     sc->dev.core = (const float*)sc->d_core;      // nullptr: no queue order by ray class
     sc->dev.nee_prune = (emitOk && !(getenv("PTAMD_PRUNE") && atoi(getenv("PTAMD_PRUNE")) == 0)) ? 1 : 0;      // PTAMD_PRUNE=0: A/B only
     sc->dev.n_nodes = n_wide; sc->dev.n_tris = n_tris; sc->dev.n_lights = n_lights; sc->dev.n_spheres = n_spheres;

@@ -68,6 +68,7 @@ struct DevScene {
     int32_t n_nodes, n_tris, n_lights, n_spheres;
     int32_t nee_prune;        // 1: every emittance in the scene is finite, >= 0 and <= 1e8, so dead NEE terms need no shadow ray (pt_stream.h: bounce)
     int32_t n_quad;           // records in `quad`; the first min(n_quad, 1024) are numbered breadth-first
+    int32_t quad_depth;       // levels of the 4-wide tree (a walk with a per-lane stack needs 3 * quad_depth + 2 entries)
     const float* core;        // 6 floats, lo.xyz hi.xyz: the box around the scene's SMALL triangles (nullptr: none) — a ray whose segment misses it can
                               // only meet the few big ones and is short; such rays are queued last (pt_stream.h: ray_is_short). Scheduling only.
 };

@@ -674,10 +674,74 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
 // one lane per stream, state in registers, rays traced in place (trace_closest), same
 // shade_step.  Pending time-sliced traversals are simply redone (they are deterministic).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlockThreads)
+constexpr int kDrainQuadStack = 40;      // per-lane stack entries of wf_drain's 4-wide walk (40 KB of LDS per workgroup): trees up to 12 levels, the config scenes' depth
+#ifndef DRAIN_MINBLOCKS
+#define DRAIN_MINBLOCKS 1      // workgroups per CU the register allocation of wf_drain must allow: 1 = free (189 VGPRs with the 4-wide walk: 2 waves/SIMD), 3 = 168 VGPRs (16 spilled)
+#endif
+// One step of one lane's walk through the 4-wide quantised tree, for wf_drain: wf_trace's node step (the box arithmetic is that kernel's,
+// statement by statement) or its pair-record leaf test, whichever `cur` asks for; returns true when the ray is finished.  The closest
+// hit does not depend on the order of tests (tie rule), and a shadow ray may stop at any hit below `stopBelow` (pt_stream.h:
+// shadow_stop_t) exactly as it does there.  The caller guarantees 3 * quad_depth + 2 <= kDrainQuadStack.
+PT_DEV bool quad_step(const DevScene& sc, const f3& org, const f3& dir, const f3& inv, float cscale, bool degenerate, float stopBelow,
+                      int* stack, int& cur, int& sp, float& bestT, int& bestPrim)
+{
+    if (cur >= 0) {
+        const uint4* np = sc.quad + 4 * (size_t)cur;
+        const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+        const float Ax = inv.x * __uint_as_float(n0.w), Ay = inv.y * __uint_as_float(n3.z), Az = inv.z * __uint_as_float(n3.w);
+        const float Bx = (__uint_as_float(n0.x) - org.x) * inv.x;
+        const float By = (__uint_as_float(n0.y) - org.y) * inv.y;
+        const float Bz = (__uint_as_float(n0.z) - org.z) * inv.z;
+        const float kSl = 9.5367431640625e-7f;                           // 2^-20
+        const float sx = (__builtin_fabsf(Bx) + 255.f * __builtin_fabsf(Ax)) * kSl;
+        const float sy = (__builtin_fabsf(By) + 255.f * __builtin_fabsf(Ay)) * kSl;
+        const float sz = (__builtin_fabsf(Bz) + 255.f * __builtin_fabsf(Az)) * kSl;
+        const float Bnx = Bx - sx, Bfx = Bx + sx, Bny = By - sy, Bfy = By + sy, Bnz = Bz - sz, Bfz = Bz + sz;
+        const uint32_t mx = (uint32_t)(__float_as_int(inv.x) >> 31), my = (uint32_t)(__float_as_int(inv.y) >> 31), mz = (uint32_t)(__float_as_int(inv.z) >> 31);
+        const uint32_t swx = (n2.x ^ n2.w) & mx, swy = (n2.y ^ n3.x) & my, swz = (n2.z ^ n3.y) & mz;
+        const uint32_t nqx = n2.x ^ swx, fqx = n2.w ^ swx, nqy = n2.y ^ swy, fqy = n3.x ^ swy, nqz = n2.z ^ swz, fqz = n3.y ^ swz;
+        const float cullT = bestT * cscale;
+        int key[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float tnx = __builtin_fmaf((float)((nqx >> (8 * k)) & 0xffu), Ax, Bnx);
+            const float tny = __builtin_fmaf((float)((nqy >> (8 * k)) & 0xffu), Ay, Bny);
+            const float tnz = __builtin_fmaf((float)((nqz >> (8 * k)) & 0xffu), Az, Bnz);
+            const float tfx = __builtin_fmaf((float)((fqx >> (8 * k)) & 0xffu), Ax, Bfx);
+            const float tfy = __builtin_fmaf((float)((fqy >> (8 * k)) & 0xffu), Ay, Bfy);
+            const float tfz = __builtin_fmaf((float)((fqz >> (8 * k)) & 0xffu), Az, Bfz);
+            const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.f));
+            const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, cullT));
+            key[k] = (tn <= tf) ? __float_as_int(tn) : 0x7fffffff;
+        }
+        int k0 = key[0], k1 = key[1], k2 = key[2], k3 = key[3], r0 = (int)n1.x, r1 = (int)n1.y, r2 = (int)n1.z, r3 = (int)n1.w;
+#define PT_CE(ka, ra, kb, rb) { const bool sw = ka > kb; const int tk = sw ? kb : ka, tr = sw ? rb : ra; kb = sw ? ka : kb; rb = sw ? ra : rb; ka = tk; ra = tr; }
+        PT_CE(k0, r0, k1, r1) PT_CE(k2, r2, k3, r3) PT_CE(k0, r0, k2, r2) PT_CE(k1, r1, k3, r3) PT_CE(k1, r1, k2, r2)
+#undef PT_CE
+        if (k0 != 0x7fffffff) {
+            if (k3 != 0x7fffffff) { stack[sp * 64] = r3; sp++; }
+            if (k2 != 0x7fffffff) { stack[sp * 64] = r2; sp++; }
+            if (k1 != 0x7fffffff) { stack[sp * 64] = r1; sp++; }
+            cur = r0;
+            return false;
+        }
+    } else {
+        const int code = ~cur;
+        int first = code >> 3, cnt = code & 7;
+        while (cnt > 0) { tri_test_pairrec(sc, first, cnt > 1, org, dir, inv, degenerate, bestT, bestPrim); first += 2; cnt -= 2; }
+        if (bestPrim >= 0 && bestT < stopBelow) return true;
+    }
+    if (sp == 0) return true;
+    sp--;
+    cur = stack[sp * 64];
+    return false;
+}
+
+template <bool QUAD>      // QUAD: walk the 4-wide tree (trace_quad); the host picks it when the walk fits the per-lane stack
+__global__ __launch_bounds__(kBlockThreads, DRAIN_MINBLOCKS)
 void wf_drain(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, int listIn, int spreadShift)
 {
-    __shared__ int lds_stack[kWavesPerBlock][kStackDepth * 64];
+    __shared__ int lds_stack[kWavesPerBlock][(QUAD ? kDrainQuadStack : kStackDepth) * 64];
     const uint32_t nIn = b.cnt[slotIn].nActive;
     // spreadShift: only every 2^s-th lane carries a stream.  The kernel is bound by latency (a wave steps at the pace of its slowest
     // lane, every bounce), and the chip is far from full at this point: thinner waves wait for the maximum of fewer paths
@@ -692,12 +756,46 @@ void wf_drain(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
     for (;;) {
         float2 hitP = make_float2(0.f, __int_as_float(-1)), hitS = hitP, hitA = hitP;
         TraceStats ts{0, 0, 0};
+        if (QUAD) {
+            // The rays of this bounce (second-to-last shadow ray, shadow ray, path ray: any subset) in ONE flat loop: a lane that has finished a ray
+            // sets up its next one inside the loop, so the wave waits for the lane with the most steps in all — not, as with one
+            // loop per ray kind, for the slowest lane of each kind in turn.
+            int todo = ((st.flags & F_SHADOWA) ? 1 : 0) | ((st.flags & F_SHADOW) ? 2 : 0) | ((st.flags & F_PATH) ? 4 : 0);
+            f3 org(0.f, 0.f, 0.f), dir(0.f, 0.f, 1.f), inv(0.f, 0.f, 0.f);
+            float cscale = 0.f, bestT = 0.f, stopBelow = 0.f;
+            bool degenerate = false;
+            int bestPrim = -1, cur = 0, sp = 0, kind = -1;
+            for (;;) {
+                if (kind < 0) {
+                    if (todo == 0) break;
+                    kind = __builtin_ctz((unsigned)todo); todo &= todo - 1;
+                    if (kind == 0) {
+                        const float4 ao = b.ray_o[2][sid], ad = b.ray_d[2][sid];
+                        org = f3(ao.x, ao.y, ao.z); dir = f3(ad.x, ad.y, ad.z); bestT = ao.w; stopBelow = ad.w;
+                    } else if (kind == 1) { org = st.shO; dir = st.shD; bestT = st.shTmax; stopBelow = shadow_stop_t(st.shO, st.shTmax); }
+                    else { org = st.pathO; dir = st.pathD; bestT = 999999.f; stopBelow = -__builtin_inff(); }
+                    ray_setup(dir, inv, cscale, degenerate);
+                    bestPrim = -1; cur = 0; sp = 0;
+                }
+                if (quad_step(sc, org, dir, inv, cscale, degenerate, stopBelow, stack, cur, sp, bestT, bestPrim)) {
+                    for (int s = 0; s < sc.n_spheres; s++) {      // spheres, in order, against the triangles' closest t (CudaUtil.cuh:137-145)
+                        const float4 c = sc.spheres[4 * s];
+                        float root;
+                        if (sphere_root(f3(c.x, c.y, c.z), c.w, org, dir, bestT, root)) { bestT = root; bestPrim = sc.n_tris + s; }
+                    }
+                    const float2 h = make_float2(bestT, __int_as_float(bestPrim));
+                    if (kind == 0) hitA = h; else if (kind == 1) hitS = h; else hitP = h;
+                    kind = -1;
+                }
+            }
+        } else {
         if (st.flags & F_SHADOWA) {
             const float4 ao = b.ray_o[2][sid], ad = b.ray_d[2][sid];
             float t; const int prim = trace_closest<false>(sc, f3(ao.x, ao.y, ao.z), f3(ad.x, ad.y, ad.z), ao.w, stack, t, ts); hitA = make_float2(t, __int_as_float(prim));
         }
         if (st.flags & F_SHADOW) { float t; const int prim = trace_closest<false>(sc, st.shO, st.shD, st.shTmax, stack, t, ts); hitS = make_float2(t, __int_as_float(prim)); }
         if (st.flags & F_PATH) { float t; const int prim = trace_closest<false>(sc, st.pathO, st.pathD, 999999.f, stack, t, ts); hitP = make_float2(t, __int_as_float(prim)); }
+        }
         if (shade_step(sc, cam, prm, b, sid, st, hitP, hitS, hitA)) break;
     }
     write_mean(b, prm, sid, st);
@@ -848,6 +946,7 @@ struct WfTuning {
     int earlyPrio;       // PTAMD_EPRIO issue priority of the traversal waves while the early phase runs beside them (no effect measured)
     bool pubOnly;        // PTAMD_EPUB  A/B: device-scope hit stores and marks, but no early phase
     int drainSpread;     // PTAMD_DSPREAD  wf_drain: at most every 2^this-th lane carries a stream (3)
+    int drainQuad;       // PTAMD_DQUAD    wf_drain walks the 4-wide tree (1; 0 = the binary tree of the one-kernel mode, A/B)
     bool tracePool;      // PTAMD_TPOOL with PTAMD_TSTAT=2: also the pooled per-wave histograms (tools/wave_exit_hist.py) — their atomics lengthen the launch tail
     int traceDump;       // PTAMD_TDUMP with PTAMD_TSTAT=2: the wf_trace launch (iteration) whose waves are dumped one by one (pt_dbg_trace_timeline -3003 / -3004)
     int traceStat;       // PTAMD_TSTAT 1 trip counters + histograms (slower build), 2 timeline only (production code path), 3 trip counters + section clocks
@@ -868,6 +967,7 @@ static const WfTuning& wf_tuning()
         w.traceStat = (int)num("PTAMD_TSTAT", 0);
         w.traceDump = (int)num("PTAMD_TDUMP", -1);
         w.tracePool = num("PTAMD_TPOOL", 0) != 0;
+        w.drainQuad = num("PTAMD_DQUAD", 1) != 0 ? 1 : 0;
         w.drainSpread = (int)num("PTAMD_DSPREAD", 3); if (w.drainSpread < 0) w.drainSpread = 0; if (w.drainSpread > 5) w.drainSpread = 5;
         return w;
     }();
@@ -959,11 +1059,15 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
         liveBound = h_cnt[0];
         if (h_cnt[0] <= (uint32_t)drainBelow) {
             // few streams left: finish them in one launch instead of hundreds of latency-bound iterations
-            // 3 waves per SIMD of wf_drain fit (165 VGPRs): spread the streams over at most that many lanes
+            // the 4-wide tree if its walk fits the per-lane stack (any tree the builder makes for the config scenes does), else the binary one
+            const bool quadWalk = tn.drainQuad && 3 * sc->quad_depth + 2 <= kDrainQuadStack;
+            // 2 (4-wide walk: 189 VGPRs) or 3 (165) waves per SIMD of wf_drain fit: spread the streams over at most that many lanes
+            const size_t drainLanes = (size_t)((quadWalk && DRAIN_MINBLOCKS < 3) ? 2 : 3) * 4 * 256 * 64;
             int spread = 0;
-            while (spread < tn.drainSpread && ((size_t)h_cnt[0] << (spread + 1)) <= (size_t)3 * 4 * 256 * 64) spread++;
+            while (spread < tn.drainSpread && ((size_t)h_cnt[0] << (spread + 1)) <= drainLanes) spread++;
             const int db = (int)((((size_t)h_cnt[0] << spread) + kBlockThreads - 1) / kBlockThreads);
-            hipLaunchKernelGGL(wf_drain, dim3(db), dim3(kBlockThreads), 0, stream, *sc, *cam, prm, b, it % 3, it & 1, spread);
+            if (quadWalk) hipLaunchKernelGGL(wf_drain<true>, dim3(db), dim3(kBlockThreads), 0, stream, *sc, *cam, prm, b, it % 3, it & 1, spread);
+            else hipLaunchKernelGGL(wf_drain<false>, dim3(db), dim3(kBlockThreads), 0, stream, *sc, *cam, prm, b, it % 3, it & 1, spread);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
             break;
