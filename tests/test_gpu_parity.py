@@ -446,6 +446,29 @@ def test_error_paths():
         ptamd.Scene(bad, tris)
 
 
+def test_drain_kernel_on_the_config_scene_tree_equals_the_pipeline():
+    """wf_drain (the run-to-completion launch that takes over a render's last live streams, on by default) walks the 4-wide tree with a 40-entry
+    per-lane stack: on the bunny stand-in of configs[2] — a tree of the depth that stack is sized for — a frame finished entirely by it, one
+    handed over half-way and one rendered by the pipeline alone are the same bits, and all equal the CPU oracle."""
+    prims = ptamd.gen_scene(1, 187)
+    nodes, tris, _ = ptamd.build_bvh(prims)
+    sc = ptamd.Scene(nodes, tris)
+    cam = ptamd.make_camera(96, 54)
+    prm = ptamd.default_params(passes=2, spp_per_pass=6)
+    sc.set_drain_threshold(0)
+    a = sc.render(cam, prm)
+    it0 = sc.last_iterations()
+    sc.set_drain_threshold(1 << 30)
+    b = sc.render(cam, prm)
+    sc.set_drain_threshold(3000)
+    c = sc.render(cam, prm)
+    assert sc.last_iterations() < it0
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(a.view(np.uint32), c.view(np.uint32))
+    O.set_libm(1)
+    img, _ = O.Scene(nodes.tobytes(), tris).render(O.make_camera(96, 54), O.make_params(96, 54, 2, 6), 16)
+    _check_image(a, img, "drain kernel, bunny stand-in")
+
+
 def test_wavefront_pipeline_equals_state_machine_kernel():
     """The two render paths (queue-driven pipeline, one-kernel state machine) are bit-identical,
     including refraction chains, on a frame that is not tile-aligned."""
