@@ -102,9 +102,7 @@ typedef struct PtParams {                                        /* the referenc
     int32_t max_refract;      /* the literal 8 of `RefractCnt++>8`, include/CudaUtil.cuh:354 */
     int32_t first_pass;       /* SampleIDX of the first pass of this call (seed = offset + SampleIDX*W*H, srcs/pathtracer.cu:71) */
     /* Tile split (new; the reference is single-device).  The frame is cut into 8x8-pixel
-     * tiles numbered row-major; every group of `world` consecutive tiles holds one tile of each rank
-     * (a rank's local tile k lies in group k; inside a group the ranks are rotated by a hash of the group
-     * number so that no rank gets the same columns in every tile row: pt_tile_map, csrc/pt_tilemap.h).
+     * tiles numbered row-major; this call renders tiles t with t % world == rank.
      * world = 1, rank = 0 renders the whole frame. */
     int32_t rank, world;
 } PtParams;
@@ -169,9 +167,6 @@ PT_API int  pt_render_tiles(PtScene* s, const PtCamera* cam, const PtParams* prm
                             float* d_tiles, void* d_work, void* hip_stream);
 PT_API int  pt_untile(const float* d_gathered, const PtCamera* cam, int32_t world,
                       float* d_frame_rgb, void* hip_stream);
-/* The tile split's index map, host only (no GPU needed): for every tile of the frame (row-major, ceil(W/8) x ceil(H/8) of them) the rank
- * that renders it and its position in that rank's tile buffer — what pt_render_tiles lays out and pt_untile undoes. */
-PT_API int  pt_tile_map(const PtCamera* cam, int32_t world, int32_t* rank_of_tile, int32_t* local_of_tile);
 PT_API int  pt_render(PtScene* s, const PtCamera* cam, const PtParams* prm, float* h_accum_rgb);
 /* Duration of the most recent pt_render_tiles launch sequence on this scene, measured with
  * HIP events on the stream it was launched on (ms), and the kernel's own work counters. */
@@ -184,7 +179,7 @@ PT_API int  pt_render_timings(PtScene* s, float* ms_out, int32_t cap, int32_t re
 
 /* ----------------------------------------------------------------------------------
  * (e) Multi-GPU exchange (new: the reference is single-device, srcs/pathtracer.cu:124-259).  One process per GPU; rank r
- * renders its tiles (pt_tile_map) with pt_render_tiles, then ONE collective — a gather of the tile buffers to rank 0,
+ * renders tiles t % world == r with pt_render_tiles, then ONE collective — a gather of the tile buffers to rank 0,
  * RCCL ncclGather (rccl.h:745) over xGMI — and pt_untile on rank 0 assemble the frame.  No torch, no MPI needed:
  *   rank 0:  pt_comm_unique_id(id) and hand the 128 bytes to the other processes (any channel), or let
  *            pt_comm_create_from_file do it through a file for the processes of one node;

@@ -21,7 +21,7 @@
 extern "C" {
 hipError_t ptk_render_units(const ptd::DevScene*, const ptd::DevCamera*, const ptd::DevParams*, float*, unsigned int*, void*, int, int, hipStream_t);
 hipError_t ptk_sum_passes(const float*, int, long long, float*, hipStream_t);
-hipError_t ptk_untile(const float*, int, int, int, int, int, int, long long, float*, hipStream_t);
+hipError_t ptk_untile(const float*, int, int, int, int, int, long long, float*, hipStream_t);
 hipError_t ptk_dbg_raycast(const ptd::DevScene*, const float*, int, float*, int*, hipStream_t);
 hipError_t ptk_dbg_bxdf(int, const float*, int, float*, hipStream_t);
 hipError_t ptk_dbg_rng(unsigned long long, int, uint32_t*, float*, hipStream_t);
@@ -327,24 +327,6 @@ int64_t pt_scene_device_bytes(const PtScene* s) { return s ? s->bytes : 0; }
 static const int kTraceBlocks = (getenv("PTAMD_TB") && atoi(getenv("PTAMD_TB")) >= 1) ? (atoi(getenv("PTAMD_TB")) > 16384 ? 16384 : atoi(getenv("PTAMD_TB"))) : 1792;
 
 // ---- geometry of the tile split --------------------------------------------------------
-// csrc/pt_tilemap.h: the arrangement of the ranks inside a group of `world` tiles; one value per process (PTAMD_TILEMAP: 0 = t % world, 1 = rotated by
-// tile row, 2 = rotated by a hash of the group, the default)
-static int tile_mode()
-{
-    static const int m = [] { const char* e = getenv("PTAMD_TILEMAP"); const int v = e ? atoi(e) : 2; return (v >= 0 && v <= 2) ? v : 2; }();
-    return m;
-}
-PT_API int pt_tile_map(const PtCamera* cam, int32_t world, int32_t* rank_of_tile, int32_t* local_of_tile)
-{
-    if (!cam || world < 1 || cam->W < 1 || cam->H < 1 || !rank_of_tile || !local_of_tile) { pt_set_error("pt_tile_map: bad argument"); return PT_ERR_INVALID; }
-    const uint32_t tiles_x = (uint32_t)((cam->W + ptd::kTile - 1) / ptd::kTile), tiles_y = (uint32_t)((cam->H + ptd::kTile - 1) / ptd::kTile);
-    for (uint32_t t = 0; t < tiles_x * tiles_y; t++) {
-        uint32_t r, lt;
-        ptd::tm_owner(t, (uint32_t)world, tiles_x, tile_mode(), r, lt);
-        rank_of_tile[t] = (int32_t)r; local_of_tile[t] = (int32_t)lt;
-    }
-    return PT_OK;
-}
 static int fill_params(const PtCamera* cam, const PtParams* prm, ptd::DevParams& d)
 {
     if (!cam || !prm) { pt_set_error("NULL camera/params"); return PT_ERR_INVALID; }
@@ -361,7 +343,7 @@ static int fill_params(const PtCamera* cam, const PtParams* prm, ptd::DevParams&
     if (maxseed > 0x7fffffffLL) { pt_set_error("offset + SampleIDX*W*H overflows int (srcs/pathtracer.cu:71)"); return PT_ERR_INVALID; }
     d.passes = prm->passes; d.spp_per_pass = prm->spp_per_pass; d.max_bounce = prm->max_bounce; d.rr_bounce = prm->rr_bounce;
     d.rr_floor = prm->rr_floor; d.max_refract = prm->max_refract; d.first_pass = prm->first_pass;
-    d.rank = prm->rank; d.world = prm->world; d.tile_mode = tile_mode();
+    d.rank = prm->rank; d.world = prm->world;
     d.tiles_x = (cam->W + ptd::kTile - 1) / ptd::kTile;
     d.tiles_y = (cam->H + ptd::kTile - 1) / ptd::kTile;
     d.n_tiles_total = d.tiles_x * d.tiles_y;
@@ -456,7 +438,7 @@ int pt_untile(const float* d_gathered, const PtCamera* cam, int32_t world, float
     const int tiles_x = (cam->W + ptd::kTile - 1) / ptd::kTile, tiles_y = (cam->H + ptd::kTile - 1) / ptd::kTile;
     const int n_total = tiles_x * tiles_y;
     const long long per_rank = (long long)((n_total + world - 1) / world) * ptd::kTilePixels * 3;
-    HIPCHK(ptk_untile(d_gathered, cam->W, cam->H, tiles_x, n_total, world, tile_mode(), per_rank, d_frame_rgb, (hipStream_t)hip_stream));
+    HIPCHK(ptk_untile(d_gathered, cam->W, cam->H, tiles_x, n_total, world, per_rank, d_frame_rgb, (hipStream_t)hip_stream));
     return PT_OK;
 }
 

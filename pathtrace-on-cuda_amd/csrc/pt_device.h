@@ -38,7 +38,6 @@
 //  light (64 B, 4 x float4): V0 V1 V2 normal area (13 f)            — srcs/pathtracer.cu:164-174
 //  sphere (64 B, 4 x float4): center rad | material (12 f)
 #pragma once
-#include "pt_tilemap.h"
 #include <stdint.h>
 
 namespace ptd {
@@ -85,7 +84,6 @@ struct DevParams {
     float rr_floor;
     int32_t max_refract, first_pass;
     int32_t rank, world;
-    int32_t tile_mode;                   // pt_tilemap.h: how the ranks are arranged inside a group of `world` tiles
     int32_t tiles_x, tiles_y, n_tiles_total, n_tiles_local;
     int32_t n_units;                     // n_tiles_local * passes (of this launch / cohort)
     int32_t unit_base;                   // first global unit of this cohort (wavefront pipeline)

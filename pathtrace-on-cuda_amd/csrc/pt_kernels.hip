@@ -64,7 +64,7 @@ void render_units(DevScene sc, DevCamera cam, DevParams prm, float* __restrict__
         // neighbouring tiles (shared BVH working set in L2).
         const int pass_rel = (int)(unit / (unsigned)prm.n_tiles_local);
         const int lt = (int)(unit % (unsigned)prm.n_tiles_local);
-        const int tile = (int)tm_tile_of((uint32_t)lt, (uint32_t)prm.rank, (uint32_t)prm.world, (uint32_t)prm.tiles_x, prm.tile_mode);
+        const int tile = lt * prm.world + prm.rank;
         const int tx = tile % prm.tiles_x, ty = tile / prm.tiles_x;
         const int px = tx * kTile + (lane & 7), py = ty * kTile + (lane >> 3);
         const int pass = prm.first_pass + pass_rel;
@@ -217,15 +217,14 @@ __global__ void sum_passes(const float* __restrict__ staging, int passes, long l
 }
 
 // gathered tile buffers (rank-major) -> row-major frame
-__global__ void untile(const float* __restrict__ gathered, int W, int H, int tiles_x, int n_tiles_total, int world, int tile_mode,
+__global__ void untile(const float* __restrict__ gathered, int W, int H, int tiles_x, int n_tiles_total, int world,
                        long long floats_per_rank, float* __restrict__ frame)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)W * H) return;
     const int px = (int)(i % W), py = (int)(i / W);
     const int tile = (py / kTile) * tiles_x + (px / kTile);
-    uint32_t rank, lt;
-    tm_owner((uint32_t)tile, (uint32_t)world, (uint32_t)tiles_x, tile_mode, rank, lt);
+    const int rank = tile % world, lt = tile / world;
     const int lane = (py % kTile) * kTile + (px % kTile);
     const float* src = gathered + (long long)rank * floats_per_rank + ((long long)lt * kTilePixels + lane) * 3;
     frame[3 * i + 0] = src[0]; frame[3 * i + 1] = src[1]; frame[3 * i + 2] = src[2];
@@ -347,13 +346,13 @@ hipError_t ptk_sum_passes(const float* staging, int passes, long long floats_per
     return hipGetLastError();
 }
 
-hipError_t ptk_untile(const float* gathered, int W, int H, int tiles_x, int n_tiles_total, int world, int tile_mode,
+hipError_t ptk_untile(const float* gathered, int W, int H, int tiles_x, int n_tiles_total, int world,
                       long long floats_per_rank, float* frame, hipStream_t stream)
 {
     const int bs = 256;
     const long long n = (long long)W * H;
     const long long nb = (n + bs - 1) / bs;
-    if (nb > 0) hipLaunchKernelGGL(ptd::untile, dim3((unsigned)nb), dim3(bs), 0, stream, gathered, W, H, tiles_x, n_tiles_total, world, tile_mode, floats_per_rank, frame);
+    if (nb > 0) hipLaunchKernelGGL(ptd::untile, dim3((unsigned)nb), dim3(bs), 0, stream, gathered, W, H, tiles_x, n_tiles_total, world, floats_per_rank, frame);
     return hipGetLastError();
 }
 

@@ -123,7 +123,7 @@ void wf_init(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, uint32_t nStrea
         const uint32_t unit = (uint32_t)prm.unit_base + (sid >> 6), lane = sid & 63;
         const int pass_rel = (int)(unit / (uint32_t)prm.n_tiles_local);
         const int lt = (int)(unit % (uint32_t)prm.n_tiles_local);
-        const int tile = (int)tm_tile_of((uint32_t)lt, (uint32_t)prm.rank, (uint32_t)prm.world, (uint32_t)prm.tiles_x, prm.tile_mode);
+        const int tile = lt * prm.world + prm.rank;
         const int tx = tile % prm.tiles_x, ty = tile / prm.tiles_x;
         const int px = tx * kTile + (int)(lane & 7), py = ty * kTile + (int)(lane >> 3);
         const int pass = prm.first_pass + pass_rel;

@@ -64,7 +64,6 @@ API = [
     ("pt_work_bytes", C.c_int64, [C.POINTER(PtCamera), C.POINTER(PtParams)]),
     ("pt_render_tiles", C.c_int, [_P, C.POINTER(PtCamera), C.POINTER(PtParams), _P, _P, _P]),
     ("pt_untile", C.c_int, [_P, C.POINTER(PtCamera), C.c_int32, _P, _P]),
-    ("pt_tile_map", C.c_int, [C.POINTER(PtCamera), C.c_int32, _P, _P]),
     ("pt_render", C.c_int, [_P, C.POINTER(PtCamera), C.POINTER(PtParams), _P]),
     ("pt_last_render_ms", C.c_int, [_P, C.POINTER(C.c_float)]),
     ("pt_render_timings", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
@@ -370,14 +369,6 @@ def work_bytes(cam, prm):
     if n < 0:
         raise PtError(lib().pt_last_error().decode())
     return n
-
-
-def tile_map(cam, world):
-    """pt_tile_map: (rank_of_tile, local_of_tile), int32 arrays over the frame's 8x8 tiles in row-major order (host only)."""
-    n = ((cam.W + TILE - 1) // TILE) * ((cam.H + TILE - 1) // TILE)
-    r, l = np.zeros(n, np.int32), np.zeros(n, np.int32)
-    _check(lib().pt_tile_map(C.byref(cam), world, _ptr(r), _ptr(l)), "pt_tile_map")
-    return r, l
 
 
 def untile(d_gathered_ptr, cam, world, d_frame_ptr, stream_ptr=0):

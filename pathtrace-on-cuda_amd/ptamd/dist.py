@@ -1,9 +1,8 @@
 """Tile-split rendering across the GPUs of one node: one process per GPU, one gather.
 
 The reference is single-device (no cudaSetDevice, no collectives: SURVEY.md F7).  Here the
-frame is cut into 8x8 tiles numbered row-major; every group of `world` consecutive tiles holds one tile
-of each rank (pt_tile_map: which one is rotated by a hash of the group, so that no rank renders the same
-columns in every tile row); a rank renders its tiles for all passes into a compact tile-major buffer (pt_render_tiles), and ONE collective — a
+frame is cut into 8x8 tiles numbered row-major; rank r renders tiles t with t % world == r
+for all passes into a compact tile-major buffer (pt_render_tiles), and ONE collective — a
 gather of the finished tile buffers to rank 0 over RCCL/xGMI — assembles the frame, which
 rank 0 de-interleaves with pt_untile.  Pixels never communicate and a pixel's seed depends
 only on (pixel offset, pass) (srcs/pathtracer.cu:71), so the N-GPU frame is bit-identical
@@ -26,12 +25,10 @@ def untile_index(W, H, world):
     """Pure index math of pt_untile: for every pixel (row-major) the position of its float3
     in the rank-major concatenation of tile buffers.  Used by the CPU/gloo tests and as the
     specification of the HIP `untile` kernel."""
-    from . import make_camera, tile_map
     tx, _, _, per_rank = tile_counts(W, H, world)
     py, px = np.divmod(np.arange(W * H, dtype=np.int64), W)
     tile = (py // TILE) * tx + (px // TILE)
-    rank_of, local_of = tile_map(make_camera(W, H), world)
-    rank, lt = rank_of[tile].astype(np.int64), local_of[tile].astype(np.int64)
+    rank, lt = tile % world, tile // world
     lane = (py % TILE) * TILE + (px % TILE)
     return rank * (per_rank * TILE * TILE) + lt * (TILE * TILE) + lane
 
