@@ -30,6 +30,18 @@ def same_bits_or_nan(a, b):
     return (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
 
 
+@pytest.fixture(autouse=True, params=["tail_in_wf_drain", "pipeline_to_the_end"])
+def _render_tail(request, monkeypatch):
+    """Every test of this file runs twice: with the library's default hand-over of a render's last live streams to wf_drain (80,000: the
+    small renders used here are then finished by that kernel after their first 16 bounce iterations) and with the pipeline running to
+    the last stream (PTAMD_DRAIN=0, read when a scene is created) — both paths must give the oracle's bits."""
+    if request.param == "pipeline_to_the_end":
+        monkeypatch.setenv("PTAMD_DRAIN", "0")
+    else:
+        monkeypatch.delenv("PTAMD_DRAIN", raising=False)
+    yield
+
+
 @pytest.fixture(scope="module", autouse=True)
 def _contract():
     import torch
