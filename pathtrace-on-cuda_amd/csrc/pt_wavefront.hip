@@ -671,8 +671,10 @@ void wf_shade(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, in
 // them serve only the few pixels whose every path runs the full depth (a render of 256 spp
 // needs ~1800 iterations while the average stream is done after ~730).  Once few streams are
 // left, per-launch latency — not throughput — sets the pace, so they are handed to this kernel:
-// one lane per stream, state in registers, rays traced in place (trace_closest), same
-// shade_step.  Pending time-sliced traversals are simply redone (they are deterministic).
+// one lane per stream (every 2^spreadShift-th lane: the kernel is bound by latency, so thinner waves are faster), state in
+// registers, rays traced in place (quad_step on the 4-wide tree, or trace_closest on the binary one when that walk would not fit
+// the per-lane stack), same shade_step.  Pending time-sliced traversals are simply redone (they are deterministic).
+// On by default for the last 80,000 live streams of a render (pt_api.hip: drain_below).
 // ---------------------------------------------------------------------------------------
 constexpr int kDrainQuadStack = 40;      // per-lane stack entries of wf_drain's 4-wide walk (40 KB of LDS per workgroup): trees up to 12 levels, the config scenes' depth
 #ifndef DRAIN_MINBLOCKS
@@ -737,7 +739,7 @@ PT_DEV bool quad_step(const DevScene& sc, const f3& org, const f3& dir, const f3
     return false;
 }
 
-template <bool QUAD>      // QUAD: walk the 4-wide tree (trace_quad); the host picks it when the walk fits the per-lane stack
+template <bool QUAD>      // QUAD: walk the 4-wide tree (quad_step); the host picks it when the walk fits the per-lane stack
 __global__ __launch_bounds__(kBlockThreads, DRAIN_MINBLOCKS)
 void wf_drain(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, int slotIn, int listIn, int spreadShift)
 {
