@@ -45,7 +45,10 @@ constexpr int kWfOvfLevels = 48;     // further levels spill to global memory (n
 constexpr int kWfChunk = 128;        // most ray ids a wave takes from a queue shard per atomic (measured optimum 116-229)
 constexpr int kWfRefill = 24;        // refill lanes once this many are idle (measured: 8..16 -2 %, 32 -0.4 %)
 constexpr int kDone = (int)0x80000000;
-constexpr uint32_t kShardBlock = 2048;   // queue indices per block of the shard interleave (a power of two)
+#ifndef SHARD_BLOCK
+#define SHARD_BLOCK 2048
+#endif
+constexpr uint32_t kShardBlock = SHARD_BLOCK;   // queue indices per block of the shard interleave (a power of two)
 // wf_trace's waves per SIMD.  7 (72 VGPRs) rather than 8 (64): the two-triangle leaf test needs the room, and
 // the kernel is bound by VALU issue, not by latency hiding (measured: 8 waves with 6-9 spilled registers and 6 waves
 // with none are both slower; round 2 again: 8 waves +5 % kernel time).
