@@ -1079,7 +1079,7 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
         }
         if (it > hardCap) return hipErrorLaunchFailure;      // cannot happen for a well-formed scene; never spin forever
         if (poll < 64) poll *= 2;
-        if (drainBelow > 0 && h_cnt[0] <= (uint32_t)drainBelow * 8u) poll = 16;      // near the hand-over: look again soon
+        if (drainBelow > 0 && (unsigned long long)h_cnt[0] <= (unsigned long long)drainBelow * 8ull) poll = 16;      // near the hand-over: look again soon
     }
     if (iters_out) *iters_out = it;
     if (trace_ev_used) *trace_ev_used = trace_ev ? (it < trace_ev_pairs ? it : trace_ev_pairs) : 0;
