@@ -552,7 +552,13 @@ PT_API int pt_set_shade_rounds(PtScene* s, int32_t mode)
 // Ask the next pt_render_tiles on this scene to run the counting build of the kernel.
 int pt_dbg_trace_timeline(PtScene* s, int64_t* out3n, int32_t n_launches)
 {
-    if (!s || !out3n || (n_launches < -2700 && (n_launches > -3000 || n_launches < -3004)) || n_launches > 2700) { pt_set_error("pt_dbg_trace_timeline: bad arguments"); return PT_ERR_INVALID; }
+    if (!s || !out3n || (n_launches < -2700 && (n_launches > -3000 || n_launches < -3005)) || n_launches > 2700) { pt_set_error("pt_dbg_trace_timeline: bad arguments"); return PT_ERR_INVALID; }
+    if (n_launches == -3005) {      // PTAMD_TSTAT=2: the raw timeline stripes, 2700 launches x kStatStripes x 3 int64 (maxima of ~start, ~dry, end per stripe of workgroups)
+        HIPCHK(hipSetDevice(s->device));
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(out3n, (const char*)s->d_counters + ptd::kStatStripeOff, (size_t)2700 * ptd::kStatStripes * 24, hipMemcpyDeviceToHost));
+        return PT_OK;
+    }
     if (n_launches == -3003 || n_launches == -3004) {      // PTAMD_TSTAT=2 + PTAMD_TDUMP=launch: 8 x int64 per wave (kStatWaves) / the per-trip log (kStatLogWaves x kStatLogTrips uint32)
         HIPCHK(hipSetDevice(s->device));
         HIPCHK(hipDeviceSynchronize());

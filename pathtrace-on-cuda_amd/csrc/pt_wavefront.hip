@@ -164,7 +164,7 @@ void wf_init(DevScene sc, DevCamera cam, DevParams prm, WfBuf b, uint32_t nStrea
 template <int MODE, bool PUBLISH = false>      // PUBLISH: hits are stored device-coherently (wf_shade PHASE 1 reads them while this kernel drains);  MODE: 0 production, 1 trip counters + histograms + timeline (PTAMD_TSTAT=1), 2 timeline only (PTAMD_TSTAT=2), 3 trip counters + section clocks, no per-step atomics (PTAMD_TSTAT=3)
 __global__ __launch_bounds__(256, TRACE_WAVES)
 void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chunkShift, int budgetShift, int budgetMin, int guideShift, int triTrig, int refillMin,
-              int topWant, unsigned long long* stat, int statLaunch, int helpShards)
+              int topWant, unsigned long long* stat, int statLaunch, int helpShards, int lateBudget)
 {
     constexpr bool STAT = MODE == 1 || MODE == 3, HIST = MODE == 1, timeline = MODE != 0;
     // PUBLISH launches share the chip with wf_shade's early phase: the traversal is the critical path of the iteration (its last waves
@@ -353,7 +353,10 @@ void wf_trace(DevScene sc, WfBuf b, int slot, int ovfStride, int parity, int chu
             // (The classic while-while shape made 64 lanes wait for the slowest lane to reach a leaf every
             // round — 24 % VALU lane utilisation; running both paths every trip, "if-if", gave 29 %.)
             if (cur >= 0) {
-                if (steps >= budget) {
+                // lateBudget (PTAMD_LB, default 64): once the queue is dry and this wave is down to its last two rays, a ray that has already done
+                // that many node steps is suspended like one that has spent its budget — the launch then does not wait for a lone ray of several
+                // hundred steps (it goes on in the next launch, from the start and among full waves)
+                if (steps >= ((lateBudget > 0 && exhausted && nIdle >= 62) ? lateBudget : budget)) {
                     // node budget spent: suspend (or, if the pool is full, carry on)
                     const uint32_t rec = atomicAdd(&b.cnt[slot].nSusp, 1u);
                     if (rec < b.suspCap) {
@@ -938,6 +941,11 @@ struct WfTuning {
     int helpShards;      // PTAMD_HELP shards a wave tries (its own included) before it takes the queue to be dry: 4 (16 = all: every wave then
                          // spends 16 returning atomics on hot words at the end of every launch; the shards are interleaved and equally long, so
                          // there is little to help with: 16 -> 4 is +1 % on configs[2], +3 % on configs[1], +4.5 % for an 8-way rank, r03_b20.log)
+    int lateBudget;      // PTAMD_LB   node steps after which a ray is suspended once the queue is dry and its wave holds at most two rays: 64 (0 = never).
+                         // An 8-way rank's big launches wait 15 us on average (20 % of them > 25 us, 3 % > 100 us) for the latest of their 64 stripes of
+                         // waves — one ray of several hundred steps, alone on its SIMD (tools/straggler_cost.py, r03_b41.log); cut there it goes on in
+                         // the next launch among full waves, and no iteration is added: 4-way rank +3 %, 8-way +0.4 ... +2.5 %, configs[2] / [3] / [4]
+                         // +0.3 / +0.5 / +1.2 % (32: -4 %, 48 / 96 / 128 within 1 % of 64; r03_b42.log, r03_b43.log)
     int topNodes;        // PTAMD_TOP  quad nodes staged in LDS (TRACE_TOP_NODES builds only)
     // wf_shade: 4 waves/SIMD (126 VGPRs, nothing spilled since the library is built without the SLP vectoriser) in 512-thread workgroups =
     // two per CU; other shapes: 256 threads -4 %, 384 / 768 -13 %, 1024 -8 %, 3 waves/SIMD -9...-13 % (r02_t16_shade_shapes_after_noslp.log)
@@ -965,6 +973,7 @@ static const WfTuning& wf_tuning()
         w.chunkShift = (int)num("PTAMD_CS", 12); w.guideShift = (int)num("PTAMD_GS", 9);
         w.budgetShift = (int)num("PTAMD_BS", 14); w.budgetMin = (int)num("PTAMD_BM", ptd::kWfBudget);
         w.refillMin = (int)num("PTAMD_RF", ptd::kWfRefill); w.triTrig = (int)num("PTAMD_TT", 64); w.topNodes = (int)num("PTAMD_TOP", ptd::kTopNodes);
+        w.lateBudget = (int)num("PTAMD_LB", 64);
         w.helpShards = (int)num("PTAMD_HELP", 4); if (w.helpShards < 1) w.helpShards = 1; if (w.helpShards > ptd::kWfShards) w.helpShards = ptd::kWfShards;
         w.shadeWaves = (int)num("PTAMD_SW", 4); w.shadeThreads = threads("PTAMD_ST", 512);
         w.trStreams = (uint32_t)num("PTAMD_TRS", 4000000);
@@ -1033,11 +1042,11 @@ static hipError_t run_cohort(int device, const ptd::DevScene* sc, const ptd::Dev
                 if ((e = hipEventRecord(evOvl[it & 1], stream)) != hipSuccess) return e;
                 if ((e = hipStreamWaitEvent(aux, evOvl[it & 1], 0)) != hipSuccess) return e;
             }
-            if (traceStat && traceStatClk) hipLaunchKernelGGL(wf_trace<3>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699, tn.helpShards);
-            else if (traceStat && traceStatFull) hipLaunchKernelGGL(wf_trace<1>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699, tn.helpShards);
-            else if (traceStat) hipLaunchKernelGGL(wf_trace<2>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699, tn.helpShards);
-            else if (early || pubOnly) hipLaunchKernelGGL((wf_trace<0, true>), dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, earlyPrio, tn.helpShards);
-            else hipLaunchKernelGGL(wf_trace<0>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, 0, tn.helpShards);
+            if (traceStat && traceStatClk) hipLaunchKernelGGL(wf_trace<3>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699, tn.helpShards, tn.lateBudget);
+            else if (traceStat && traceStatFull) hipLaunchKernelGGL(wf_trace<1>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699, tn.helpShards, tn.lateBudget);
+            else if (traceStat) hipLaunchKernelGGL(wf_trace<2>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, traceStat, it < 2700 ? it : 2699, tn.helpShards, tn.lateBudget);
+            else if (early || pubOnly) hipLaunchKernelGGL((wf_trace<0, true>), dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, earlyPrio, tn.helpShards, tn.lateBudget);
+            else hipLaunchKernelGGL(wf_trace<0>, dim3(tb), dim3(256), 0, stream, *sc, b, sIn, ovfStride, it & 1, chunkShift, budgetShift, budgetMin, guideShift, triTrig, refillMin, topNodes, (unsigned long long*)nullptr, 0, tn.helpShards, tn.lateBudget);
             if (timed) (void)hipEventRecord(trace_ev[3 * it + 1], stream);
             const dim3 sg((liveBound + shadeThreads - 1) / shadeThreads), sb(shadeThreads);
             const bool twoRounds = shadeRounds >= 0 ? (shadeRounds != 0) : (liveBound < trStreams);
